@@ -1,0 +1,275 @@
+"""CPU oracle for the STAR nugget hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU restatement (numpy for the integer / index work,
+torch-CPU fp32 for the differentiable float work) of the reference algorithms
+listed below.  It is the *checker* for the HIP kernels in ``star_amd/csrc``.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it; nothing under ``star_amd/`` does.
+
+Parity status: PINNED.  Every function below is checked by
+``tests/test_oracle_golden.py`` against golden vectors in ``tests/golden/*.npz``
+that were produced by importing the true reference from ``/root/reference`` in
+the build container (script: ``tests/golden/gen_golden.py``).
+
+Reference lines restated (all paths relative to the reference checkout):
+  scorer                      src/models/w2v_asr.py:113-117,553
+  nugget_counts / topk_select src/models/w2v_asr.py:208-244
+  type_table                  src/models/w2v_asr.py:316-323
+  gather_rows                 src/models/w2v_asr.py:566-567, w2v_simul.py:427,446-447
+  quantity_loss               src/models/w2v_simul.py:419-424
+  resize                      src/models/w2v_simul.py:504-535
+  fire_scan / block mask      src/models/w2v_simul.py:196-220,376-403
+  xattn_core                  src/models/my_transformer.py:535-603
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+F32_MIN = float(np.finfo(np.float32).min)
+F32_MAX = float(np.finfo(np.float32).max)
+
+
+# --------------------------------------------------------------------------- a1
+def scorer(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
+           w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """scores[B,T] = w2 . relu(W1 x + b1) + b2   (w2v_asr.py:113-117,553).
+
+    w1 is in nn.Linear layout [out, in]; w2 is [1, d]; b2 is [1].
+    """
+    h = torch.relu(x @ w1.t() + b1)
+    return (h @ w2.t() + b2).squeeze(-1)
+
+
+# --------------------------------------------------------------------------- a2
+def nugget_counts(n_tok: np.ndarray, rate: float) -> np.ndarray:
+    """k_b = trunc(fp32(n_tok) * fp32(1/rate) + 0.99), clamped to n_tok.
+
+    w2v_asr.py:219-221.  The reference multiplies an int64 tensor by a Python
+    float, which torch evaluates in fp32 with one rounding per op (mul, add).
+    """
+    n = np.asarray(n_tok, dtype=np.int64)
+    ratio = np.float32(1.0 / rate)
+    k = (n.astype(np.float32) * ratio).astype(np.float32) + np.float32(0.99)
+    k = k.astype(np.float32).astype(np.int64)
+    return np.minimum(k, n)
+
+
+def topk_select(scores: np.ndarray, attn_mask: np.ndarray, rate: float | None = None,
+                n_nugget: np.ndarray | None = None):
+    """Per-utterance top-k anchor selection (w2v_asr.py:208-244).
+
+    Returns (nugget_mask[B,K] bool, indices_ascending[B,K] int64,
+    scores_gather[B,K] fp32).  Ordering rule restated: rank all T frames by
+    (selection key descending, frame index ascending); keys are the scores with
+    pad frames at finfo.min and the last valid frame forced to finfo.max.  The
+    first k_b ranks are the kept set, ranks k_b..K-1 are the pad slots; each of
+    the two groups is emitted in ascending frame order, kept group first.
+
+    Ties: the reference ranks with torch's NON-stable CPU sort (w2v_asr.py:238), whose order
+    among equal keys is an artefact of the sort kernel (e.g. 40 equal keys come back as
+    [30, 21, 22, ...]); it only matters for pad slots that reach into padded frames and for
+    exactly equal scores.  This restatement (and the HIP kernel) define the tie rule as
+    "lower frame index first"; tests compare with the reference up to that tie rule.
+    """
+    scores = np.asarray(scores, dtype=np.float32)
+    mask = np.asarray(attn_mask).astype(bool)
+    bsz, t = scores.shape
+    n_tok = mask.sum(axis=1).astype(np.int64)
+    if n_nugget is None:
+        n_nugget = nugget_counts(n_tok, rate)
+    n_nugget = np.asarray(n_nugget, dtype=np.int64)
+    kmax = int(n_nugget.max())
+    keys = scores.copy()
+    keys[~mask] = F32_MIN
+    # python-style negative index when n_tok == 0 (torch scatter would raise); n_tok>=1 is required
+    keys[np.arange(bsz), n_tok - 1] = F32_MAX
+    idx_out = np.zeros((bsz, kmax), dtype=np.int64)
+    frame = np.arange(t, dtype=np.int64)
+    for b in range(bsz):
+        # lexsort: last key is primary.  -keys turns "descending" into ascending and
+        # maps -0.0/+0.0 to values that still compare equal, so ties fall to the frame index.
+        order = np.lexsort((frame, -keys[b].astype(np.float64)))[:kmax]
+        kb = int(n_nugget[b])
+        idx_out[b, :kb] = np.sort(order[:kb])
+        idx_out[b, kb:] = np.sort(order[kb:])
+    nugget_mask = np.arange(kmax)[None, :] < n_nugget[:, None]
+    scores_gather = np.take_along_axis(scores, idx_out, axis=1)
+    return nugget_mask, idx_out, scores_gather
+
+
+# --------------------------------------------------------------------------- a3
+def type_table(t: int, nugget_indices: np.ndarray, nugget_mask: np.ndarray):
+    """w2v_asr.py:316-323: 0/1 table [B,T] with ones at kept frames; indices with pads = -1."""
+    idx = np.asarray(nugget_indices, dtype=np.int64).copy()
+    idx[~np.asarray(nugget_mask, dtype=bool)] = -1
+    bsz = idx.shape[0]
+    table = np.zeros((bsz, t + 1), dtype=np.int64)
+    for b in range(bsz):
+        table[b, idx[b]] = 1          # -1 lands in the spare column t, sliced off below
+    return table[:, :t], idx
+
+
+# --------------------------------------------------------------------------- a4
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """mem[b,j,:] = src[b, idx[b,j], :] with idx == -1 addressing the LAST frame
+    (w2v_asr.py:566-567; w2v_simul.py:427,446-447).  Differentiable (scatter-add)."""
+    b = torch.arange(src.shape[0]).unsqueeze(1)
+    return src[b, idx]
+
+
+# --------------------------------------------------------------------------- a5
+def quantity_loss(scores: torch.Tensor, attn_mask: torch.Tensor,
+                  target_lengths: torch.Tensor, threshold: float = 1.0):
+    """alphas = sigmoid(s)*mask; q = mean_b((sum_t alphas/thr - L_b)^2)  (w2v_simul.py:419-424)."""
+    alphas = torch.sigmoid(scores) * attn_mask
+    q = ((alphas / threshold).sum(dim=1) - target_lengths) ** 2
+    return alphas, q.mean()
+
+
+# --------------------------------------------------------------------------- a6
+def resize(alphas: torch.Tensor, target_lengths: torch.Tensor, threshold: float = 1.0,
+           max_rounds: int = 10) -> torch.Tensor:
+    """CIF weight rescale + halve-and-add-mean fix-ups (w2v_simul.py:504-535, noise = 0).
+
+    Rows are independent, so the reference's batch-global loop is restated per row:
+    each of up to ``max_rounds`` rounds snapshots the columns with value > thr, visits
+    them in ascending order and, if the *current* value is still >= thr, replaces the row
+    by 0.5*row + (0.5*sum(row)/nnz(row))*(row != 0).  A row with no offender in a round is
+    finished (nothing else can change it).  Sums use torch's fp32 CPU reduction so that
+    the restatement matches the reference bit-for-bit on the golden vectors.
+    """
+    a = alphas.detach().to(torch.float32).clone()
+    num = target_lengths.to(torch.float32)
+    den = a.sum(-1)
+    a = a * (num / den)[:, None]
+    thr = float(threshold)
+    for b in range(a.shape[0]):
+        row = a[b]
+        for _ in range(max_rounds):
+            offenders = torch.nonzero(row > thr).flatten().tolist()
+            if not offenders:
+                break
+            for y in offenders:
+                if float(row[y]) >= thr:
+                    nz = row.ne(0).to(torch.float32)
+                    mean = 0.5 * row.sum() / nz.sum()
+                    row = row * 0.5 + mean * nz
+        a[b] = row
+    return a
+
+
+# --------------------------------------------------------------------------- a7
+def fire_scan(alphas: np.ndarray, attn_mask: np.ndarray, with_block_mask: bool = True):
+    """Cumulative-score integrate-and-fire (w2v_simul.py:376-403 + 196-220).
+
+    Sequential fp32 recurrence per row over ALL T frames (pads contribute 0 but can
+    still fire if the carry is >= 1):  cur = fl(cur + a_t); fire = cur >= 1 or t == n_b-1;
+    cur = fl(cur - 1) where fired.  Returns (nugget_mask[B,Kf] bool,
+    nugget_indices[B,Kf] int64 ascending, -1 padded, block_attn_mask[B,T,T] fp32 or None)
+    with block[b,i,j] = 1 iff  last_fire_before(i) < j <= i  and frame i is valid.
+    """
+    m = np.asarray(attn_mask).astype(bool)
+    a = np.asarray(alphas, dtype=np.float32) * m.astype(np.float32)
+    bsz, t = a.shape
+    src_len = m.sum(axis=1).astype(np.int64)
+    cur = np.zeros(bsz, dtype=np.float32)
+    one = np.float32(1.0)
+    fires = np.zeros((bsz, t), dtype=bool)
+    for i in range(t):
+        cur = (cur + a[:, i]).astype(np.float32)
+        f = (cur >= one) | (src_len == i + 1)
+        cur = np.where(f, (cur - one).astype(np.float32), cur)
+        fires[:, i] = f
+    counts = fires.sum(axis=1)
+    kf = int(counts.max())
+    idx = np.full((bsz, kf), -1, dtype=np.int64)
+    for b in range(bsz):
+        pos = np.flatnonzero(fires[b])
+        idx[b, :pos.size] = pos
+    nugget_mask = idx != -1
+    block = None
+    if with_block_mask:
+        block = block_mask_from_fires(idx, m)
+    return nugget_mask, idx, block
+
+
+def block_mask_from_fires(nugget_indices: np.ndarray, attn_mask: np.ndarray) -> np.ndarray:
+    """block[b,i,j] = 1.0 iff prev_fire(i) < j <= i and attn_mask[b,i]; prev_fire(i) is the
+    largest fire position strictly below i (-1 if none).  w2v_simul.py:382-402."""
+    m = np.asarray(attn_mask).astype(bool)
+    bsz, t = m.shape
+    out = np.zeros((bsz, t, t), dtype=np.float32)
+    j = np.arange(t)
+    for b in range(bsz):
+        prev = -1
+        fired = set(int(v) for v in nugget_indices[b] if v >= 0)
+        for i in range(t):
+            if m[b, i]:
+                out[b, i] = ((j > prev) & (j <= i)).astype(np.float32)
+            if i in fired:
+                prev = i
+    return out
+
+
+# --------------------------------------------------------------------------- a8
+def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+               key_mask: torch.Tensor | None, scorer_logits: torch.Tensor | None,
+               limit_cross_attn: bool = False, scale: bool = True):
+    """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch,
+    dropout p = 0, head_mask None).
+
+    q [B,h,L,hd], k/v [B,h,K,hd], key_mask [B,K] bool (True = attend), scorer_logits [B,Kb]
+    with Kb <= K (zero-extended, my_transformer.py:114-125 variant).  Returns (O, P).
+    """
+    a = q @ k.transpose(-1, -2)
+    if scale:
+        a = a / (v.shape[-1] ** 0.5)
+    lq, lk = a.shape[-2], a.shape[-1]
+    fmin = torch.finfo(a.dtype).min
+    if limit_cross_attn:
+        i = torch.arange(lq).unsqueeze(1)
+        j = torch.arange(lk).unsqueeze(0)
+        allowed = (j - i) <= 2
+        ilk = torch.where(allowed, torch.ones((), dtype=a.dtype), torch.full((), fmin, dtype=a.dtype))
+        a = a + ilk
+    if key_mask is not None:
+        add = (1.0 - key_mask.to(a.dtype)) * fmin          # invert_attention_mask semantics
+        a = a + add[:, None, None, :]
+    if scorer_logits is not None:
+        s = scorer_logits
+        if s.shape[1] < lk:
+            s = torch.cat([s, s.new_zeros(s.shape[0], lk - s.shape[1])], dim=1)
+        a = a + s[:, None, None, :].to(a.dtype)
+    p = torch.softmax(a, dim=-1)
+    return p @ v, p
+
+
+# ------------------------------------------------------------------ composite step (bench/smoke)
+def nugget_step_asr(x, s_repr, lengths, rate, w1, b1, w2, b2, qs, kv_scales, gs):
+    """One NuggetStep of the non-streaming path, fp32 on CPU.
+
+    x [B,T,d] scorer input, s_repr [B,T,d] semantic states, lengths list[int], qs list of
+    [B,h,L,hd] queries (one per layer), kv_scales list of (ak[d], av[d]) fixed diagonal K/V
+    maps, gs list of cotangents like qs.  Returns dict with scores, indices, loss.
+    """
+    bsz, t, d = x.shape
+    h = qs[0].shape[1]
+    mask = torch.arange(t)[None, :] < torch.tensor(lengths)[:, None]
+    scores = scorer(x, w1, b1, w2, b2)
+    nmask, idx, _ = topk_select(scores.detach().numpy(), mask.numpy(), rate)
+    idx_t = torch.from_numpy(idx)
+    nmask_t = torch.from_numpy(nmask)
+    sg = scores.gather(1, idx_t)
+    table, pos = type_table(t, idx, nmask)
+    mem = gather_rows(s_repr, idx_t)
+    loss = x.new_zeros(())
+    for q, (ak, av), g in zip(qs, kv_scales, gs):
+        kk = (mem * ak).view(bsz, -1, h, d // h).transpose(1, 2)
+        vv = (mem * av).view(bsz, -1, h, d // h).transpose(1, 2)
+        o, _ = xattn_core(q, kk, vv, nmask_t, sg, False)
+        loss = loss + (o * g).sum()
+    return {"scores": scores, "indices": idx, "mask": nmask, "table": table, "positions": pos,
+            "scores_gather": sg, "mem": mem, "loss": loss}

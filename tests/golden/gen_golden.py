@@ -1,0 +1,181 @@
+"""Generate golden vectors for the nugget hot path FROM THE TRUE REFERENCE.
+
+Run ONLY in the build container (the reference does not travel to the GPU box):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 HF_HUB_OFFLINE=1 \
+        python tests/golden/gen_golden.py
+
+It imports the reference's own functions (SURVEY.md section 8c recipe: the two absent
+packages the reference imports but never uses on this path, torchaudio and
+audiolm_pytorch, get empty in-memory placeholder modules), feeds them small seeded inputs
+and stores inputs + reference outputs as .npz data files next to this script.  Nothing from
+the reference's source text is stored -- only arrays.
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("STAR_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+
+import transformers  # noqa: E402,F401  (must be imported before the placeholders)
+
+for name, attrs in (("torchaudio", {}), ("torchaudio.functional", {"resample": None}),
+                    ("audiolm_pytorch", {}), ("audiolm_pytorch.version", {"__version__": "1.5.7"})):
+    if name not in sys.modules:
+        mod = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+
+from src.models import w2v_asr, w2v_simul, my_transformer  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(1)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+def len_mask(lengths, t):
+    return torch.arange(t)[None, :] < torch.tensor(lengths)[:, None]
+
+
+# ------------------------------------------------------------------ a2 + a3: top-k select
+def gen_select():
+    asr = w2v_asr.W2VASRModel
+    cases = []
+    g = torch.Generator().manual_seed(11)
+    # (a) config-1 shaped
+    cases.append(("c1", torch.randn(4, 250, generator=g), [250, 230, 200, 170], 4))
+    # (b) heavy ties
+    cases.append(("ties", (torch.randn(3, 37, generator=g) * 2).round() / 2, [37, 30, 11], 3))
+    # (c) n_tok = 1 and K > n_tok rows (pad slots reach into padded frames)
+    cases.append(("short", torch.randn(4, 40, generator=g), [1, 40, 7, 2], 2))
+    # (d) rate 12, T not a multiple of 64
+    cases.append(("r12", torch.randn(5, 101, generator=g), [101, 99, 64, 65, 13], 12))
+    # (e) signed zeros and duplicates of the extreme values
+    z = torch.zeros(2, 16)
+    z[0, ::2] = -0.0
+    z[0, 3] = 1.0
+    z[1, 5:9] = torch.tensor([-0.0, 0.0, -0.0, 0.0])
+    z[1, :5] = -1.0
+    cases.append(("zeros", z, [16, 12], 4))
+    # (f) rate 8, rate 2
+    cases.append(("r8", torch.randn(3, 130, generator=g), [130, 128, 67], 8))
+    cases.append(("r2", torch.randn(3, 64, generator=g), [64, 63, 33], 2))
+    for name, scores, lengths, rate in cases:
+        t = scores.shape[1]
+        mask = len_mask(lengths, t)
+        me = SimpleNamespace(nugget_compress_rate=rate)
+        nmask, idx, sg = asr.apply_nugget_compression(me, torch.zeros(len(lengths), t, 2), mask,
+                                                      nugget_scores=scores.clone())
+        table, pos = asr.add_nugget_type_embedding(torch.zeros(len(lengths), t, 2), idx, nmask)
+        save("select_" + name, scores=scores, lengths=np.array(lengths), rate=np.array(rate),
+             nugget_mask=nmask, indices=idx, scores_gather=sg, type_table=table, positions=pos)
+    # nugget-count sweep (w2v_asr.py:219-221)
+    n = torch.arange(1, 3001)
+    rows = {}
+    for rate in (2, 3, 4, 8, 12, 18, 30):
+        k = (n * (1 / rate) + 0.99).to(torch.int64)
+        k[k > n] = n[k > n]
+        rows[f"r{rate}"] = k
+    save("select_counts", n=n, **rows)
+
+
+# ------------------------------------------------------------------ a5 + a6 + a7: CIF path
+def gen_cif():
+    sim = w2v_simul.W2VSimulModel
+    me = SimpleNamespace(get_valid_mask_indices=sim.get_valid_mask_indices)
+    g = torch.Generator().manual_seed(23)
+    cases = []
+    cases.append(("plain", torch.randn(4, 48, generator=g), [48, 40, 31, 17], [6, 5, 4, 3]))
+    # rows that need fix-up rounds: few valid frames, large targets, spiky scores
+    s = torch.randn(4, 24, generator=g)
+    s[0, 3] = 6.0
+    s[1, :] = -4.0
+    s[1, 5] = 5.0
+    s[1, 9] = 4.0
+    s[2, 2] = 8.0
+    cases.append(("fixup", s, [24, 20, 6, 12], [9, 7, 5, 4]))
+    cases.append(("ragged", torch.randn(6, 70, generator=g) - 1.0, [70, 69, 64, 33, 5, 1], [8, 7, 7, 4, 2, 1]))
+    for name, scores, lengths, tgt in cases:
+        t = scores.shape[1]
+        mask = len_mask(lengths, t)
+        tl = torch.tensor(tgt)
+        alphas = torch.sigmoid(scores) * mask
+        q = (((alphas / 1).sum(dim=1) - tl) ** 2).mean()
+        resized = sim.resize(me, alphas.clone(), tl)
+        nmask, idx, block = sim.apply_threshold_yield_nugget(me, resized.clone().detach(), mask)
+        save("cif_" + name, scores=scores, lengths=np.array(lengths), target_lengths=tl,
+             alphas=alphas, quantity_loss=q, resized=resized, nugget_mask=nmask,
+             nugget_indices=idx, block_attn_mask=block)
+    # scan-only cases on hand-made alphas (values > 1, carry past the last valid frame)
+    a = torch.tensor([[0.5, 0.6, 2.5, 0.0, 0.1, 0.0, 0.0, 0.0],
+                      [0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3],
+                      [1.0, 1.0, 0.999999, 1e-7, 0.5, 0.5, 0.0, 0.0]], dtype=torch.float32)
+    lengths = [5, 8, 6]
+    mask = len_mask(lengths, 8)
+    nmask, idx, block = sim.apply_threshold_yield_nugget(me, a.clone(), mask)
+    save("cif_scan_handmade", alphas=a, lengths=np.array(lengths), nugget_mask=nmask,
+         nugget_indices=idx, block_attn_mask=block)
+
+
+# ------------------------------------------------------------------ a8: score-biased attention core
+def gen_xattn():
+    att = my_transformer.MyGPT2Attention
+    g = torch.Generator().manual_seed(37)
+    cases = [("small", 2, 2, 5, 7, 8, [7, 4], False),
+             ("ilk", 2, 2, 6, 7, 8, [7, 5], True),
+             ("ilk_wide", 1, 3, 4, 12, 16, [9], True),
+             ("hd96", 2, 2, 9, 21, 96, [21, 13], False)]
+    for name, b, h, lq, lk, hd, klen, ilk in cases:
+        q = torch.randn(b, h, lq, hd, generator=g).requires_grad_()
+        k = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        v = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        sc = torch.randn(b, lk, generator=g).requires_grad_()
+        gout = torch.randn(b, h, lq, hd, generator=g)
+        kmask = len_mask(klen, lk)
+        add = (1.0 - kmask[:, None, None, :].to(torch.float32)) * torch.finfo(torch.float32).min
+        me = SimpleNamespace(scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
+                             is_cross_attention=True, layer_idx=0, attn_dropout=torch.nn.Identity())
+        o, p = att._attn(me, q, k, v, add, None, sc, limit_cross_attn=ilk)
+        (o * gout).sum().backward()
+        save("xattn_" + name, q=q, k=k, v=v, scores=sc, key_lengths=np.array(klen), ilk=np.array(ilk),
+             gout=gout, o=o, p=p, dq=q.grad, dk=k.grad, dv=v.grad, dscores=sc.grad)
+
+
+# ------------------------------------------------------------------ a1: scorer (module as built at w2v_asr.py:113-117)
+def gen_scorer():
+    torch.manual_seed(5)
+    d = 32
+    from torch import nn
+    model = nn.Sequential(nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, 1))
+    x = torch.randn(3, 19, d, requires_grad=True)
+    s = model(x).squeeze(-1)
+    gs = torch.randn(3, 19)
+    (s * gs).sum().backward()
+    save("scorer_small", x=x, w1=model[0].weight, b1=model[0].bias, w2=model[2].weight, b2=model[2].bias,
+         scores=s, gscores=gs, dx=x.grad, dw1=model[0].weight.grad, db1=model[0].bias.grad,
+         dw2=model[2].weight.grad, db2=model[2].bias.grad)
+
+
+if __name__ == "__main__":
+    gen_select()
+    gen_cif()
+    gen_xattn()
+    gen_scorer()

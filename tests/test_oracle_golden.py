@@ -1,0 +1,148 @@
+"""The CPU oracle (oracle/nugget_oracle.py) against the reference-generated golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nugget_oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def lmask(lengths, t):
+    return np.arange(t)[None, :] < np.asarray(lengths)[:, None]
+
+
+SELECT = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "select_*.npz"))
+                if "counts" not in p)
+CIF = ["cif_plain", "cif_fixup", "cif_ragged"]
+XATTN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "xattn_*.npz")))
+
+
+def test_counts_sweep():
+    g = load("select_counts")
+    for key in g:
+        if key == "n":
+            continue
+        rate = int(key[1:])
+        np.testing.assert_array_equal(orc.nugget_counts(g["n"], rate), g[key])
+
+
+def select_keys(scores, lengths):
+    """Selection keys as the reference builds them (pads = finfo.min, last valid frame = finfo.max)."""
+    keys = np.array(scores, dtype=np.float32)
+    t = keys.shape[1]
+    keys[~lmask(lengths, t)] = np.finfo(np.float32).min
+    keys[np.arange(keys.shape[0]), np.asarray(lengths) - 1] = np.finfo(np.float32).max
+    return keys
+
+
+def assert_select_equal_up_to_ties(idx, ref_idx, nmask, keys, sg=None, ref_sg=None):
+    """Equality with the reference wherever the reference's answer is DEFINED.
+
+    The reference ranks frames with torch's non-stable CPU sort, whose order among equal keys is an
+    implementation detail of the sort kernel (it changes with row length / ISA).  Both groups
+    (kept = mask True, pad slots = mask False) must be ascending and must hold the same multiset of
+    keys as the reference; when the keys of a row are pairwise distinct this IS exact equality,
+    which is asserted on top.
+    """
+    for b in range(idx.shape[0]):
+        kb = int(nmask[b].sum())
+        for lo, hi in ((0, kb), (kb, idx.shape[1])):
+            mine, ref = idx[b, lo:hi], ref_idx[b, lo:hi]
+            assert np.all(np.diff(mine) > 0), "group must be strictly ascending"
+            np.testing.assert_array_equal(np.sort(keys[b, mine]), np.sort(keys[b, ref]))
+        sel = np.sort(keys[b, ref_idx[b]])
+        rest = np.delete(keys[b], ref_idx[b])
+        tied = (np.unique(sel).size != sel.size) or (rest.size and rest.max() >= sel.min())
+        if not tied:
+            np.testing.assert_array_equal(idx[b], ref_idx[b])
+            if sg is not None:
+                np.testing.assert_array_equal(sg[b], ref_sg[b])
+
+
+@pytest.mark.parametrize("name", SELECT)
+def test_select(name):
+    g = load(name)
+    t = g["scores"].shape[1]
+    mask = lmask(g["lengths"], t)
+    nmask, idx, sg = orc.topk_select(g["scores"], mask, float(g["rate"]))
+    np.testing.assert_array_equal(nmask, g["nugget_mask"])
+    keys = select_keys(g["scores"], g["lengths"])
+    assert_select_equal_up_to_ties(idx, g["indices"], nmask, keys, sg, g["scores_gather"])
+    np.testing.assert_array_equal(sg, np.take_along_axis(g["scores"], idx, axis=1))
+    table, pos = orc.type_table(t, idx, nmask)
+    ref_table, ref_pos = orc.type_table(t, g["indices"], g["nugget_mask"])
+    np.testing.assert_array_equal(ref_table, g["type_table"])      # type_table restatement itself
+    np.testing.assert_array_equal(ref_pos, g["positions"])
+    if np.array_equal(idx, g["indices"]):
+        np.testing.assert_array_equal(table, g["type_table"])
+        np.testing.assert_array_equal(pos, g["positions"])
+
+
+@pytest.mark.parametrize("name", CIF)
+def test_cif(name):
+    g = load(name)
+    t = g["scores"].shape[1]
+    mask = lmask(g["lengths"], t)
+    alphas, q = orc.quantity_loss(torch.from_numpy(g["scores"]), torch.from_numpy(mask),
+                                  torch.from_numpy(g["target_lengths"]))
+    np.testing.assert_array_equal(alphas.numpy(), g["alphas"])
+    np.testing.assert_allclose(q.numpy(), g["quantity_loss"], rtol=1e-6)
+    resized = orc.resize(alphas, torch.from_numpy(g["target_lengths"]))
+    np.testing.assert_array_equal(resized.numpy(), g["resized"])
+    nmask, idx, block = orc.fire_scan(g["resized"], mask)
+    np.testing.assert_array_equal(idx, g["nugget_indices"])
+    np.testing.assert_array_equal(nmask, g["nugget_mask"])
+    np.testing.assert_array_equal(block, g["block_attn_mask"])
+
+
+def test_scan_handmade():
+    g = load("cif_scan_handmade")
+    mask = lmask(g["lengths"], g["alphas"].shape[1])
+    nmask, idx, block = orc.fire_scan(g["alphas"], mask)
+    np.testing.assert_array_equal(idx, g["nugget_indices"])
+    np.testing.assert_array_equal(nmask, g["nugget_mask"])
+    np.testing.assert_array_equal(block, g["block_attn_mask"])
+
+
+@pytest.mark.parametrize("name", XATTN)
+def test_xattn(name):
+    g = load(name)
+    q, k, v, sc = (torch.from_numpy(g[n]).requires_grad_() for n in ("q", "k", "v", "scores"))
+    kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
+    o, p = orc.xattn_core(q, k, v, kmask, sc, bool(g["ilk"]))
+    (o * torch.from_numpy(g["gout"])).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o.detach().numpy(), g["o"], **tol)
+    np.testing.assert_allclose(p.detach().numpy(), g["p"], **tol)
+    np.testing.assert_allclose(q.grad.numpy(), g["dq"], **tol)
+    np.testing.assert_allclose(k.grad.numpy(), g["dk"], **tol)
+    np.testing.assert_allclose(v.grad.numpy(), g["dv"], **tol)
+    np.testing.assert_allclose(sc.grad.numpy(), g["dscores"], **tol)
+
+
+def test_scorer():
+    g = load("scorer_small")
+    x, w1, b1, w2, b2 = (torch.from_numpy(g[n]).requires_grad_() for n in ("x", "w1", "b1", "w2", "b2"))
+    s = orc.scorer(x, w1, b1, w2, b2)
+    (s * torch.from_numpy(g["gscores"])).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.detach().numpy(), g["scores"], **tol)
+    for name, t in (("dx", x), ("dw1", w1), ("db1", b1), ("dw2", w2), ("db2", b2)):
+        np.testing.assert_allclose(t.grad.numpy(), g[name], **tol)
+
+
+def test_gather_rows_negative_index():
+    src = torch.arange(2 * 5 * 3, dtype=torch.float32).view(2, 5, 3).requires_grad_()
+    idx = torch.tensor([[0, 3, -1], [4, -1, -1]])
+    mem = orc.gather_rows(src, idx)
+    assert torch.equal(mem[0, 2], src[0, 4]) and torch.equal(mem[1, 1], src[1, 4])
+    mem.sum().backward()
+    assert src.grad[1, 4, 0] == 3 and src.grad[0, 1, 0] == 0
