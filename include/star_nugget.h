@@ -1,0 +1,181 @@
+/* star_nugget.h -- C ABI of libstar_nugget.so: STAR's nugget-compression hot path on MI355X (gfx950).
+ *
+ * The reference (steventan0110/STAR) has no FFI / plugin interface: its boundary is a set of Python
+ * method signatures.  Each entry point below names the reference lines it replaces; the Python
+ * mirror of those signatures lives in star_amd/nugget.py and binds these symbols through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory,
+ *     the library never allocates or frees device memory and keeps no mutable global state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host
+ *     synchronisation and no readback, and is re-entrant;
+ *   - return value: 0 on success, a negative STAR_ERR_* otherwise; star_last_error() then returns a
+ *     thread-local message.  Nothing throws across the ABI;
+ *   - tensors are dense row-major unless strides are given (strides are in ELEMENTS);
+ *   - bf16 is the storage type of activations (uint16 bit pattern of the upper half of an fp32),
+ *     fp32 the type of scores, biases, log-sum-exps and parameter gradients.
+ */
+#ifndef STAR_NUGGET_H
+#define STAR_NUGGET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAR_OK 0
+#define STAR_ERR_ARG (-1)      /* bad shape / null pointer / unsupported size */
+#define STAR_ERR_LAUNCH (-2)   /* HIP reported a launch error */
+#define STAR_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define STAR_DT_BF16 0
+#define STAR_DT_F32 1
+
+int star_version(void);
+const char* star_last_error(void);
+
+/* ---------------------------------------------------------------- a2 + a3: top-k anchor select
+ * Replaces W2VASRModel.apply_nugget_compression (src/models/w2v_asr.py:208-244; copy at
+ * w2v_simul.py:222-260) fused with add_nugget_type_embedding (w2v_asr.py:316-323).
+ *   scores      [B,T] fp32
+ *   attn_mask   [B,T] uint8 (bool) or NULL; pads are mask==0.  When NULL, lengths[b] gives the
+ *               number of valid (leading) frames.
+ *   lengths     [B] int32 or NULL (exactly one of attn_mask / lengths must be given)
+ *   n_nugget    [B] int32 explicit nugget counts, or NULL to use trunc(n_tok*ratio + 0.99) clamped
+ *               to n_tok with fp32 arithmetic (ratio = (float)(1/compress_rate))
+ *   K           width of the outputs = max_b k_b (computed by the caller from the lengths)
+ * Outputs (any may be NULL except idx_out):
+ *   idx_out [B,K] int64 ascending kept indices then ascending pad-slot indices,
+ *   mask_out [B,K] uint8 (j < k_b), scores_gather [B,K] fp32 = scores[b, idx_out],
+ *   type_table [B,T] int64 0/1, positions [B,K] int64 (= idx_out with pad slots set to -1).
+ * Tie rule: equal keys rank by lower frame index first. */
+int star_topk_select(const float* scores, const uint8_t* attn_mask, const int32_t* lengths,
+                     const int32_t* n_nugget, float ratio, int B, int T, int K,
+                     int64_t* idx_out, uint8_t* mask_out, float* scores_gather,
+                     int64_t* type_table, int64_t* positions, void* stream);
+
+/* Stand-alone add_nugget_type_embedding (w2v_asr.py:316-323; w2v_simul.py:273-280) for callers that already
+ * hold indices and mask: type_table [B,T] int64 = 1 at kept frames, positions [B,K] int64 = idx with masked
+ * slots set to -1 (positions may be NULL). */
+int star_nugget_type_table(const int64_t* idx, const uint8_t* nugget_mask, int B, int T, int K,
+                           int64_t* type_table, int64_t* positions, void* stream);
+
+/* ---------------------------------------------------------------- a4: row gather / scatter-add
+ * Replaces semantic_repr[arange(B)[:,None], nugget_indices] (w2v_asr.py:566-567,
+ * w2v_simul.py:446-447) and, with row_bytes == 4, the score gather of w2v_simul.py:427.
+ * idx [B,K] int64; an index < 0 addresses frame T + idx (so -1 is the last frame), as in Python.
+ * row_bytes must be a multiple of 4.  src [B,T,row], dst [B,K,row]. */
+int star_gather_rows_fwd(const void* src, const int64_t* idx, void* dst, int B, int T, int K,
+                         int64_t row_bytes, void* stream);
+/* Backward of the gather: dsrc[b,t,:] = sum_{j: idx[b,j]==t} ddst[b,j,:]  (index_put accumulate),
+ * written for EVERY (b,t) (zero where no j matches), summed in ascending j with fp32 accumulation.
+ * dtype is STAR_DT_BF16 or STAR_DT_F32; d = elements per row. */
+int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* dsrc, int B, int T, int K,
+                         int d, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- a5: CIF quantity loss
+ * Replaces w2v_simul.py:419-424.  alphas = sigmoid(scores)*mask; diff_b = sum_t alphas/thr - L_b;
+ * loss = mean_b diff_b^2.  attn_mask/lengths as in star_topk_select.  target_lengths [B] int32.
+ * Outputs: alphas [B,T] fp32, diff [B] fp32, loss [1] fp32. */
+int star_cif_quantity_fwd(const float* scores, const uint8_t* attn_mask, const int32_t* lengths,
+                          const int32_t* target_lengths, float threshold, int B, int T,
+                          float* alphas, float* diff, float* loss, void* stream);
+/* dscores[b,t] (+)= gloss * 2*diff_b/(B*thr) * a*(1-a) with a = alphas[b,t]  (0 at pads).
+ * accumulate != 0 adds into dscores instead of overwriting. gloss [1] fp32 on device. */
+int star_cif_quantity_bwd(const float* alphas, const float* diff, const float* gloss,
+                          float threshold, int B, int T, int accumulate, float* dscores, void* stream);
+
+/* ---------------------------------------------------------------- a6: CIF resize
+ * Replaces W2VSimulModel.resize (w2v_simul.py:504-535, noise = 0): rescale each row to sum L_b,
+ * then up to max_rounds (reference: 10) halve-and-add-mean fix-up rounds.  Row sums accumulate in
+ * fp64 and are rounded once to fp32.  alphas [B,T] fp32 -> out [B,T] fp32 (may alias).  T <= 16384. */
+int star_cif_resize(const float* alphas, const int32_t* target_lengths, float threshold,
+                    int max_rounds, int B, int T, float* out, void* stream);
+
+/* ---------------------------------------------------------------- a7: cumulative fire scan
+ * Replaces apply_threshold_yield_nugget + get_valid_mask_indices (w2v_simul.py:376-403,196-220).
+ * Exact serial fp32 recurrence per utterance over all T frames:
+ *   cur = fl(cur + a_t*mask_t); fire = cur >= 1 || t == n_b-1; cur = fl(cur-1) if fire.
+ *   alphas [B,T] fp32; attn_mask [B,T] uint8 or NULL (then lengths [B] int32 defines a prefix mask)
+ *   cap    width of the index outputs (>= max fire count; fires beyond cap are dropped and
+ *          counted in counts, so the caller can detect overflow)
+ *   scores optional [B,T] fp32: scores_gather[b,j] = scores[b, idx] (idx -1 -> frame T-1)
+ * Outputs: idx_out [B,cap] int64 ascending fire positions, -1 padded; mask_out [B,cap] uint8;
+ *   counts [B] int32; max_count [1] int32 (max over b); scores_gather [B,cap] fp32 or NULL. */
+int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask, const int32_t* lengths,
+                       const float* scores, int B, int T, int cap, int64_t* idx_out,
+                       uint8_t* mask_out, int32_t* counts, int32_t* max_count,
+                       float* scores_gather, void* stream);
+/* block_attn_mask[b,i,j] = 1.0f iff prev_fire(i) < j <= i and frame i valid (w2v_simul.py:382-402),
+ * built on demand from the fire positions.  idx [B,cap] int64 (-1 padded), counts [B] int32,
+ * out [B,T,T] fp32. */
+int star_cif_block_mask(const int64_t* idx, const int32_t* counts, const uint8_t* attn_mask,
+                        const int32_t* lengths, int B, int T, int cap, float* out, void* stream);
+
+/* ---------------------------------------------------------------- a1: scorer MLP
+ * Replaces nugget_model = Sequential(Linear(d,d), ReLU, Linear(d,1)) + squeeze(-1)
+ * (w2v_asr.py:113-117,553; w2v_simul.py:144-148,410-411).
+ *   x   [N,d] bf16 frames (N = B*T)       w1 [d,d] bf16 in nn.Linear layout [out,in]
+ *   b1  [d] fp32   w2 [d] fp32   b2 [1] fp32 (device)      scores [N] fp32
+ * d must be a multiple of 128.  The hidden activation H is never written to memory.
+ * workspace: star_scorer_fwd_workspace(N,d) bytes (per-column-tile partial scores). */
+size_t star_scorer_fwd_workspace(int64_t N, int d);
+int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2,
+                    const float* b2, int64_t N, int d, float* scores, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* Backward for the R rows listed in rows[] (frame ids into x; the frames whose dscore is non-zero):
+ *   dscores [N] fp32 (full), rows [R] int32, w1t = transpose of w1 ([in,out] bf16) for dx.
+ * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),
+ *   dx [N,d] bf16 or NULL: rows listed in rows[] are written, all other rows must have been zeroed
+ *   by the caller.
+ * workspace: star_scorer_bwd_workspace(R,d) bytes. */
+size_t star_scorer_bwd_workspace(int64_t R, int d);
+int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1,
+                    const float* w2, const float* dscores, const int32_t* rows, int64_t R,
+                    int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* fp32 [rows,cols] -> bf16 copy and bf16 transpose (the per-step weight cast of W1). */
+int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream);
+
+/* ---------------------------------------------------------------- a8 (+a11): score-biased attention core
+ * Replaces MyGPT2Attention._attn for cross-attention (src/models/my_transformer.py:535-603):
+ *   P = softmax(Q K^T * scale + ILK + bias[b,j]),  O = P V
+ *   q [B,h,L,hd], k/v [B,h,Kn,hd], o like q: bf16 with element strides (sb, sh, sr), hd contiguous
+ *   bias [B,bias_len] fp32 or NULL: scorer logits (+ the additive encoder pad mask, if the caller
+ *        folded it in); keys j >= bias_len get bias 0 (prefix-bias variant, my_transformer.py:114-125)
+ *   key_len [B] int32 or NULL: keys j >= key_len[b] are masked (P = 0 exactly)
+ *   ilk_diag < 0: no infinite-lookback mask; otherwise key j is visible to query i iff j <= i + ilk_diag
+ *        (the reference uses 2, my_transformer.py:566)
+ *   lse [B,h,L] fp32: log-sum-exp of the masked, biased logits (saved for backward)
+ *   p_out optional [B,h,L,Kn] fp32 attention weights (output_attentions), NULL to skip
+ * hd in {64, 96, 128}. */
+typedef struct {
+    int B, h, L, Kn, hd;
+    int64_t q_sb, q_sh, q_sr;
+    int64_t k_sb, k_sh, k_sr;
+    int64_t v_sb, v_sh, v_sr;
+    int64_t o_sb, o_sh, o_sr;
+    int bias_len;
+    int ilk_diag;
+    float scale;
+} star_xattn_shape;
+
+int star_xattn_fwd(const void* q, const void* k, const void* v, const float* bias,
+                   const int32_t* key_len, const star_xattn_shape* s, void* o, float* lse,
+                   float* p_out, void* stream);
+/* Backward.  do_/o share o's strides; dq uses q's strides, dk/dv use k's/v's strides.
+ *   delta [B,h,L] fp32 scratch (row-sum of dO*O, written by the call)
+ *   dbias_part [B,h,Kn] fp32 scratch; dbias [B,bias_len] fp32 = sum over heads and queries of dS,
+ *   overwritten when accumulate == 0, added to otherwise (the reference feeds the same
+ *   scorer_logits to every decoder layer, my_transformer.py:917-928). dbias may be NULL. */
+int star_xattn_bwd(const void* q, const void* k, const void* v, const void* o, const void* do_,
+                   const float* lse, const float* bias, const int32_t* key_len,
+                   const star_xattn_shape* s, void* dq, void* dk, void* dv, float* delta,
+                   float* dbias_part, float* dbias, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAR_NUGGET_H */

@@ -1,0 +1,362 @@
+// CIF-style segmenter of the simultaneous path:
+//   quantity loss      src/models/w2v_simul.py:419-424
+//   resize             src/models/w2v_simul.py:504-535
+//   fire scan          src/models/w2v_simul.py:376-403 (+ get_valid_mask_indices 196-220)
+//   block mask         src/models/w2v_simul.py:382-402 (built lazily from the fire positions)
+// All of it is HBM/latency-bound fp32 + integer work: B*T*4 bytes in, a few KB out.
+#include "common.h"
+
+namespace star {
+
+constexpr int CIF_THREADS = 256;
+
+// block-wide sum of a double, result broadcast to every thread; red must hold >= 4 doubles.
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------ a5
+__global__ __launch_bounds__(CIF_THREADS) void cif_quantity_fwd_kernel(
+    const float* __restrict__ scores, const uint8_t* __restrict__ attn_mask, const int32_t* __restrict__ lengths,
+    const int32_t* __restrict__ target_lengths, float threshold, int T, float* __restrict__ alphas,
+    float* __restrict__ diff) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* srow = scores + (size_t)b * T;
+    const uint8_t* mrow = attn_mask ? attn_mask + (size_t)b * T : nullptr;
+    const int n = lengths ? lengths[b] : 0;
+    double acc = 0.0;
+    for (int i = tid; i < T; i += CIF_THREADS) {
+        bool valid = mrow ? (mrow[i] != 0) : (i < n);
+        // accurate expf (not __expf): alphas feed bit-exact fire decisions downstream
+        float a = valid ? 1.0f / (1.0f + expf(-srow[i])) : 0.0f;
+        alphas[(size_t)b * T + i] = a;
+        acc += (double)(a / threshold);
+    }
+    double tot = block_sum_f64(acc, red);
+    if (tid == 0) diff[b] = (float)tot - (float)target_lengths[b];
+}
+
+__global__ __launch_bounds__(CIF_THREADS) void cif_quantity_loss_kernel(const float* __restrict__ diff, int B,
+                                                                        float* __restrict__ loss) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < B; i += CIF_THREADS) acc += (double)diff[i] * (double)diff[i];
+    double tot = block_sum_f64(acc, red);
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)B);
+}
+
+__global__ __launch_bounds__(CIF_THREADS) void cif_quantity_bwd_kernel(const float* __restrict__ alphas,
+                                                                       const float* __restrict__ diff,
+                                                                       const float* __restrict__ gloss,
+                                                                       float threshold, int B, int T, int accumulate,
+                                                                       float* __restrict__ dscores) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * CIF_THREADS + threadIdx.x;
+    if (i >= T) return;
+    float a = alphas[(size_t)b * T + i];
+    float g = gloss[0] * 2.0f * diff[b] / ((float)B * threshold) * a * (1.0f - a);
+    size_t o = (size_t)b * T + i;
+    dscores[o] = accumulate ? dscores[o] + g : g;
+}
+
+// ------------------------------------------------------------------------------------------ a6
+// One workgroup per utterance; the row lives in LDS.  The reference's batch-global while-loop is
+// row-separable (a fix-up only touches its own row), so every row runs its own <= max_rounds rounds.
+__global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __restrict__ alphas,
+                                                                 const int32_t* __restrict__ target_lengths,
+                                                                 float threshold, int max_rounds, int T,
+                                                                 float* __restrict__ out) {
+    extern __shared__ float rs_smem[];
+    float* row = rs_smem;                          // [T]
+    uint32_t* snap = (uint32_t*)(row + T);         // [(T+31)/32] offender snapshot bits
+    __shared__ double red[4];
+    __shared__ int flag;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nwords = (T + 31) / 32;
+    double acc = 0.0;
+    for (int i = tid; i < T; i += CIF_THREADS) {
+        float a = alphas[(size_t)b * T + i];
+        row[i] = a;
+        acc += (double)a;
+    }
+    float den = (float)block_sum_f64(acc, red);
+    float scale = __fdiv_rn((float)target_lengths[b], den);
+    for (int i = tid; i < T; i += CIF_THREADS) row[i] = __fmul_rn(row[i], scale);
+    __syncthreads();
+    for (int round = 0; round < max_rounds; ++round) {
+        // snapshot of the offenders (value > thr), as torch.where does at the top of a round
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        for (int w = tid; w < nwords; w += CIF_THREADS) {
+            uint32_t bits = 0;
+            for (int k = 0; k < 32; ++k) {
+                int i = w * 32 + k;
+                if (i < T && row[i] > threshold) bits |= 1u << k;
+            }
+            snap[w] = bits;
+            if (bits) flag = 1;
+        }
+        __syncthreads();
+        if (!flag) break;
+        for (int w = 0; w < nwords; ++w) {
+            uint32_t bits = snap[w];  // uniform
+            while (bits) {
+                int y = w * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (row[y] >= threshold) {  // uniform: re-check the CURRENT value
+                    double s = 0.0, nz = 0.0;
+                    for (int i = tid; i < T; i += CIF_THREADS) {
+                        float a = row[i];
+                        s += (double)a;
+                        nz += (a != 0.0f) ? 1.0 : 0.0;
+                    }
+                    float sum = (float)block_sum_f64(s, red);
+                    float cnt = (float)block_sum_f64(nz, red);
+                    float mean = __fdiv_rn(__fmul_rn(0.5f, sum), cnt);
+                    for (int i = tid; i < T; i += CIF_THREADS) {
+                        float a = row[i];
+                        row[i] = __fadd_rn(__fmul_rn(a, 0.5f), (a != 0.0f) ? mean : 0.0f);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < T; i += CIF_THREADS) out[(size_t)b * T + i] = row[i];
+}
+
+// ------------------------------------------------------------------------------------------ a7
+// One wave per 64 utterances, lane = utterance: the recurrence is inherently serial in t and
+// fp32 addition is not associative, so a parallel prefix sum cannot reproduce the reference's
+// fire positions; 64 recurrences run side by side instead.  Tiles of 64 frames are loaded
+// coalesced (lane = frame), transposed through LDS (pitch 65 dwords, conflict-free), and consumed
+// lane = row.  Fire flags leave the scan as bit words; the compaction into ascending positions is
+// integer work (popcount prefix over words).
+constexpr int FS_TILE = 64;
+
+__global__ __launch_bounds__(64) void cif_fire_scan_kernel(
+    const float* __restrict__ alphas, const uint8_t* __restrict__ attn_mask, const int32_t* __restrict__ lengths,
+    const float* __restrict__ scores, int B, int T, int cap, int64_t* __restrict__ idx_out,
+    uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
+    float* __restrict__ scores_gather) {
+    extern __shared__ uint32_t fs_smem[];
+    const int nwords = (T + 31) / 32;
+    float* tile = (float*)fs_smem;                          // [64][65]
+    uint32_t* words = fs_smem + FS_TILE * (FS_TILE + 1);    // [64][nwords]
+    __shared__ int lens[64];
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * 64;
+    const int nrows = min(64, B - b0);
+    const int myrow = b0 + lane;
+    const bool active = lane < nrows;
+
+    // valid-frame count per row (== attn_mask.sum(1) of the reference)
+    if (attn_mask) {
+        for (int r = 0; r < nrows; ++r) {
+            int c = 0;
+            for (int i = lane; i < T; i += 64) c += (attn_mask[(size_t)(b0 + r) * T + i] != 0);
+            c = wave_sum(c);
+            if (lane == 0) lens[r] = c;
+        }
+    } else if (active) {
+        lens[lane] = lengths[myrow];
+    }
+    __syncthreads();
+    const int n = active ? lens[lane] : 0;
+
+    float cur = 0.0f;
+    uint32_t bits = 0;
+    for (int t0 = 0; t0 < T; t0 += FS_TILE) {
+        __syncthreads();
+        // coalesced load: for each row r, lanes read 64 consecutive frames
+        for (int r = 0; r < nrows; ++r) {
+            int t = t0 + lane;
+            float a = 0.0f;
+            if (t < T) {
+                a = alphas[(size_t)(b0 + r) * T + t];
+                bool valid = attn_mask ? (attn_mask[(size_t)(b0 + r) * T + t] != 0) : (t < lens[r]);
+                a = valid ? a : a * 0.0f;   // alphas * attn_mask (keeps NaN/inf semantics of the product)
+            }
+            tile[r * (FS_TILE + 1) + lane] = a;
+        }
+        __syncthreads();
+        const int steps = min(FS_TILE, T - t0);
+        if (active) {
+            for (int k = 0; k < steps; ++k) {
+                const int t = t0 + k;
+                float a = tile[lane * (FS_TILE + 1) + k];
+                cur = __fadd_rn(cur, a);
+                bool fire = (cur >= 1.0f) || (n == t + 1);
+                cur = fire ? __fsub_rn(cur, 1.0f) : cur;
+                bits |= (fire ? 1u : 0u) << (t & 31);
+                if ((t & 31) == 31 || t == T - 1) {
+                    words[lane * nwords + (t >> 5)] = bits;
+                    bits = 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // compaction: the wave walks the rows, lane = bit word
+    int wave_max = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int b = b0 + r;
+        int base = 0;
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            int w = w0 + lane;
+            uint32_t wb = (w < nwords) ? words[r * nwords + w] : 0u;
+            int pc = __popc(wb);
+            int incl = pc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            int pos = base + incl - pc;
+            while (wb) {
+                int t = w * 32 + __builtin_ctz(wb);
+                wb &= wb - 1;
+                if (pos < cap) {
+                    idx_out[(size_t)b * cap + pos] = t;
+                    if (mask_out) mask_out[(size_t)b * cap + pos] = 1;
+                    if (scores_gather) scores_gather[(size_t)b * cap + pos] = scores[(size_t)b * T + t];
+                }
+                ++pos;
+            }
+            base += __shfl(incl, 63, 64);
+        }
+        const float last_score = scores_gather ? scores[(size_t)b * T + (T - 1)] : 0.0f;
+        for (int j = base + lane; j < cap; j += 64) {
+            idx_out[(size_t)b * cap + j] = -1;
+            if (mask_out) mask_out[(size_t)b * cap + j] = 0;
+            if (scores_gather) scores_gather[(size_t)b * cap + j] = last_score;  // index -1 == frame T-1
+        }
+        if (lane == 0 && counts) counts[b] = base;
+        wave_max = max(wave_max, base);
+    }
+    if (lane == 0 && max_count) atomicMax(max_count, wave_max);
+}
+
+// block_attn_mask rows: out[b,i,j] = (prev_fire(i) < j <= i) && valid(i)
+__global__ __launch_bounds__(256) void cif_block_mask_kernel(const int64_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ counts,
+                                                             const uint8_t* __restrict__ attn_mask,
+                                                             const int32_t* __restrict__ lengths, int T, int cap,
+                                                             float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= T) return;
+    const int cnt = min(counts[b], cap);
+    const int64_t* irow = idx + (size_t)b * cap;
+    // prev = largest fire position < i  (binary search over the ascending positions)
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (irow[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    const int prev = lo > 0 ? (int)irow[lo - 1] : -1;
+    const bool valid = attn_mask ? (attn_mask[(size_t)b * T + i] != 0) : (i < lengths[b]);
+    float* orow = out + ((size_t)b * T + i) * T;
+    for (int j = lane; j < T; j += 64) orow[j] = (valid && j > prev && j <= i) ? 1.0f : 0.0f;
+}
+
+}  // namespace star
+
+extern "C" int star_cif_quantity_fwd(const float* scores, const uint8_t* attn_mask, const int32_t* lengths,
+                                     const int32_t* target_lengths, float threshold, int B, int T, float* alphas,
+                                     float* diff, float* loss, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(scores && target_lengths && alphas && diff && loss, "star_cif_quantity_fwd: null pointer");
+    STAR_REQUIRE((attn_mask != nullptr) != (lengths != nullptr), "star_cif_quantity_fwd: give exactly one of attn_mask / lengths");
+    STAR_REQUIRE(B >= 1 && T >= 1 && threshold > 0.f, "star_cif_quantity_fwd: bad shape B=%d T=%d", B, T);
+    hipLaunchKernelGGL(cif_quantity_fwd_kernel, dim3(B), dim3(CIF_THREADS), 0, (hipStream_t)stream, scores, attn_mask,
+                       lengths, target_lengths, threshold, T, alphas, diff);
+    hipLaunchKernelGGL(cif_quantity_loss_kernel, dim3(1), dim3(CIF_THREADS), 0, (hipStream_t)stream, diff, B, loss);
+    STAR_LAUNCH_CHECK("star_cif_quantity_fwd");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_quantity_bwd(const float* alphas, const float* diff, const float* gloss, float threshold,
+                                     int B, int T, int accumulate, float* dscores, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alphas && diff && gloss && dscores, "star_cif_quantity_bwd: null pointer");
+    STAR_REQUIRE(B >= 1 && B <= 65535 && T >= 1, "star_cif_quantity_bwd: bad shape B=%d T=%d", B, T);
+    hipLaunchKernelGGL(cif_quantity_bwd_kernel, dim3(cdiv(T, CIF_THREADS), B), dim3(CIF_THREADS), 0,
+                       (hipStream_t)stream, alphas, diff, gloss, threshold, B, T, accumulate, dscores);
+    STAR_LAUNCH_CHECK("star_cif_quantity_bwd");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_resize(const float* alphas, const int32_t* target_lengths, float threshold, int max_rounds,
+                               int B, int T, float* out, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alphas && target_lengths && out, "star_cif_resize: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && T <= 16384, "star_cif_resize: bad shape B=%d T=%d (T <= 16384)", B, T);
+    size_t smem = (size_t)T * 4 + (size_t)((T + 31) / 32) * 4;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)cif_resize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) {
+            set_error("star_cif_resize: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(cif_resize_kernel, dim3(B), dim3(CIF_THREADS), smem, (hipStream_t)stream, alphas,
+                       target_lengths, threshold, max_rounds, T, out);
+    STAR_LAUNCH_CHECK("star_cif_resize");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask, const int32_t* lengths,
+                                  const float* scores, int B, int T, int cap, int64_t* idx_out, uint8_t* mask_out,
+                                  int32_t* counts, int32_t* max_count, float* scores_gather, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alphas && idx_out, "star_cif_fire_scan: null pointer");
+    STAR_REQUIRE((attn_mask != nullptr) != (lengths != nullptr), "star_cif_fire_scan: give exactly one of attn_mask / lengths");
+    STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1, "star_cif_fire_scan: bad shape B=%d T=%d cap=%d", B, T, cap);
+    STAR_REQUIRE(!scores_gather || scores, "star_cif_fire_scan: scores_gather requested without scores");
+    const int nwords = (T + 31) / 32;
+    size_t smem = (size_t)(FS_TILE * (FS_TILE + 1) + 64 * nwords) * 4;
+    STAR_REQUIRE(smem <= 150 * 1024, "star_cif_fire_scan: T=%d needs %zu bytes of LDS", T, smem);
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)cif_fire_scan_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            set_error("star_cif_fire_scan: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    if (max_count) {
+        hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            set_error("star_cif_fire_scan: memset failed: %s", hipGetErrorString(e));
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(cif_fire_scan_kernel, dim3(cdiv(B, 64)), dim3(64), smem, (hipStream_t)stream, alphas, attn_mask,
+                       lengths, scores, B, T, cap, idx_out, mask_out, counts, max_count, scores_gather);
+    STAR_LAUNCH_CHECK("star_cif_fire_scan");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_block_mask(const int64_t* idx, const int32_t* counts, const uint8_t* attn_mask,
+                                   const int32_t* lengths, int B, int T, int cap, float* out, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(idx && counts && out, "star_cif_block_mask: null pointer");
+    STAR_REQUIRE((attn_mask != nullptr) != (lengths != nullptr), "star_cif_block_mask: give exactly one of attn_mask / lengths");
+    STAR_REQUIRE(B >= 1 && B <= 65535 && T >= 1 && cap >= 1, "star_cif_block_mask: bad shape B=%d T=%d cap=%d", B, T, cap);
+    hipLaunchKernelGGL(cif_block_mask_kernel, dim3(cdiv(T, 4), B), dim3(256), 0, (hipStream_t)stream, idx, counts,
+                       attn_mask, lengths, T, cap, out);
+    STAR_LAUNCH_CHECK("star_cif_block_mask");
+    return STAR_OK;
+}

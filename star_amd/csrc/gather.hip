@@ -1,0 +1,156 @@
+// Row gather into the padded nugget memory and its backward.
+//
+// Forward  (src/models/w2v_asr.py:566-567, w2v_simul.py:427,446-447):
+//     dst[b,j,:] = src[b, idx[b,j], :]         idx < 0 wraps like Python (-1 = last frame)
+//   one wave per output row, 16 B per lane per step (coalesced 1 KiB wave accesses).
+//   HBM bytes: read + write 2 * row_bytes * B*K.
+// Backward (autograd of the advanced index = index_put accumulate):
+//     dsrc[b,t,:] = sum_{j : idx[b,j] == t} ddst[b,j,:]
+//   destination-centric: one workgroup per (b, 64-frame tile) inverts idx for its tile in LDS, then
+//   every destination row is written exactly once (copy, zero, or ordered fp32 sum for duplicates).
+//   No atomics, no separate zero-fill pass, bitwise reproducible.
+//   HBM bytes: read row_bytes * B*K, write row_bytes * B*T.
+#include "common.h"
+
+namespace star {
+
+template <typename V>
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const V* __restrict__ src,
+                                                              const int64_t* __restrict__ idx,
+                                                              V* __restrict__ dst, int T, int K,
+                                                              int64_t rows_total, int vec_per_row) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    int64_t b = row / K;
+    int64_t t = idx[row];
+    if (t < 0) t += T;
+    if (t < 0) t = 0;
+    if (t >= T) t = T - 1;
+    const V* s = src + ((size_t)b * T + t) * vec_per_row;
+    V* d = dst + (size_t)row * vec_per_row;
+    for (int c = lane; c < vec_per_row; c += 64) d[c] = s[c];
+}
+
+constexpr int GB_TILE = 64;  // destination frames per workgroup
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Pack {
+    T v[N];
+};
+
+// T_ELEM: __bf16 or float; rows are d elements, moved VEC elements per lane per step
+// (VEC = 4 when d % 4 == 0, else 1 -- the scalar score gather of w2v_simul.py:427 has d = 1).
+template <typename T_ELEM, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __restrict__ ddst,
+                                                              const int64_t* __restrict__ idx,
+                                                              T_ELEM* __restrict__ dsrc, int T, int K, int d) {
+    __shared__ int first_j[GB_TILE];
+    __shared__ int count[GB_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * GB_TILE;
+    if (tid < GB_TILE) {
+        first_j[tid] = 0x7FFFFFFF;
+        count[tid] = 0;
+    }
+    __syncthreads();
+    const int64_t* irow = idx + (size_t)b * K;
+    for (int j = tid; j < K; j += 256) {
+        int64_t t = irow[j];
+        if (t < 0) t += T;
+        int r = (int)(t - t0);
+        if (t >= 0 && t < T && r >= 0 && r < GB_TILE) {
+            atomicAdd(&count[r], 1);
+            atomicMin(&first_j[r], j);
+        }
+    }
+    __syncthreads();
+    typedef Pack<T_ELEM, VEC> vec4;
+    const int nvec = d / VEC;
+    for (int r = wid; r < GB_TILE; r += 4) {
+        int t = t0 + r;
+        if (t >= T) break;
+        vec4* out = (vec4*)(dsrc + ((size_t)b * T + t) * d);
+        int c = count[r];
+        if (c == 0) {
+            vec4 z;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) z.v[q] = (T_ELEM)0.0f;
+            for (int v = lane; v < nvec; v += 64) out[v] = z;
+        } else if (c == 1) {
+            const vec4* in = (const vec4*)(ddst + ((size_t)b * K + first_j[r]) * d);
+            for (int v = lane; v < nvec; v += 64) out[v] = in[v];
+        } else {
+            // duplicates (only pad slots produce them in this pipeline): ordered fp32 sum
+            for (int v = lane; v < nvec; v += 64) {
+                float acc[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+                for (int j = first_j[r]; j < K; ++j) {
+                    int64_t tj = irow[j];
+                    if (tj < 0) tj += T;
+                    if (tj != t) continue;
+                    vec4 x = ((const vec4*)(ddst + ((size_t)b * K + j) * d))[v];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[q] += (float)x.v[q];
+                }
+                vec4 o;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) o.v[q] = (T_ELEM)acc[q];
+                out[v] = o;
+            }
+        }
+    }
+}
+
+}  // namespace star
+
+extern "C" int star_gather_rows_fwd(const void* src, const int64_t* idx, void* dst, int B, int T, int K,
+                                    int64_t row_bytes, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(src && idx && dst, "star_gather_rows_fwd: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && row_bytes >= 4 && row_bytes % 4 == 0,
+                 "star_gather_rows_fwd: bad shape B=%d T=%d K=%d row_bytes=%lld", B, T, K, (long long)row_bytes);
+    int64_t rows = (int64_t)B * K;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    bool a16 = (row_bytes % 16 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (a16)
+        hipLaunchKernelGGL(gather_rows_fwd_kernel<u32x4>, grid, block, 0, (hipStream_t)stream, (const u32x4*)src,
+                           idx, (u32x4*)dst, T, K, rows, (int)(row_bytes / 16));
+    else
+        hipLaunchKernelGGL(gather_rows_fwd_kernel<uint32_t>, grid, block, 0, (hipStream_t)stream,
+                           (const uint32_t*)src, idx, (uint32_t*)dst, T, K, rows, (int)(row_bytes / 4));
+    STAR_LAUNCH_CHECK("star_gather_rows_fwd");
+    return STAR_OK;
+}
+
+extern "C" int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* dsrc, int B, int T, int K, int d,
+                                    int dtype, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(ddst && idx && dsrc, "star_gather_rows_bwd: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && d >= 1, "star_gather_rows_bwd: bad shape B=%d T=%d K=%d d=%d", B, T, K, d);
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_gather_rows_bwd: bad dtype %d", dtype);
+    STAR_REQUIRE(B <= 65535, "star_gather_rows_bwd: B=%d exceeds grid.y", B);
+    dim3 grid(cdiv(T, GB_TILE), B), block(256);
+    const int esz = dtype == STAR_DT_BF16 ? 2 : 4;
+    const bool v4 = (d % 4 == 0) && (((uintptr_t)ddst | (uintptr_t)dsrc) % (4 * esz) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == STAR_DT_BF16) {
+        if (v4)
+            hipLaunchKernelGGL((gather_rows_bwd_kernel<__bf16, 4>), grid, block, 0, st, (const __bf16*)ddst, idx,
+                               (__bf16*)dsrc, T, K, d);
+        else
+            hipLaunchKernelGGL((gather_rows_bwd_kernel<__bf16, 1>), grid, block, 0, st, (const __bf16*)ddst, idx,
+                               (__bf16*)dsrc, T, K, d);
+    } else {
+        if (v4)
+            hipLaunchKernelGGL((gather_rows_bwd_kernel<float, 4>), grid, block, 0, st, (const float*)ddst, idx,
+                               (float*)dsrc, T, K, d);
+        else
+            hipLaunchKernelGGL((gather_rows_bwd_kernel<float, 1>), grid, block, 0, st, (const float*)ddst, idx,
+                               (float*)dsrc, T, K, d);
+    }
+    STAR_LAUNCH_CHECK("star_gather_rows_bwd");
+    return STAR_OK;
+}

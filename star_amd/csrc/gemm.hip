@@ -1,0 +1,525 @@
+// Scorer MLP on bf16 MFMA.
+//
+// Reference: nugget_model = Sequential(Linear(d,d), ReLU, Linear(d,1)) + squeeze(-1)
+// (src/models/w2v_asr.py:113-117,553; w2v_simul.py:144-148,410-411).  The reference materialises
+// H = relu(X W1^T + b1) ([B,T,d]) and runs a second GEMV; here the second layer is the epilogue of
+// the first GEMM, so H never leaves the registers:
+//     scores[m] = b2 + sum_n w2[n] * relu( sum_k X[m,k] W1[n,k] + b1[n] )
+//
+// One "NT" GEMM template (C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous) serves forward
+// and backward through its epilogue:
+//   EPI_SCORE   relu/bias/w2 row-dot  -> per-column-tile partial scores      (forward)
+//   EPI_DH      G = ds[m]*w2[n]*(H>0) -> G, G^T (bf16) + column partials for dw2/db1   (backward 1)
+//   EPI_SLAB    fp32 split-K slab store                                      (dW1 = G^T X)
+//   EPI_ROWS    bf16 store with row scatter                                  (dX = G W1)
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 mfma_f32_16x16x32_bf16.
+// Operands are staged with global_load_lds (16 B/lane, LDS image lane-linear) into two LDS buffers;
+// the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the
+// per-lane SOURCE address and to the read address (same involution on both sides).
+// Workgroup -> tile mapping is XCD-aware: the column tiles of one row panel run on one XCD, so the
+// A panel is fetched into one L2 instead of eight.
+// Algorithmic work: forward 2*N_f*d*(d+1) FLOP; bytes: X 2*d*N_f + W1 2*d*d read, scores 4*N_f written.
+#include "common.h"
+
+namespace star {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 KiB
+
+enum { EPI_SCORE = 0, EPI_DH = 1, EPI_SLAB = 2, EPI_ROWS = 3 };
+
+struct GemmParams {
+    const __bf16* A;
+    const __bf16* B;
+    int64_t lda, ldb;
+    int M, N;                 // logical sizes (rows of A / rows of B)
+    int kchunks;              // K / 64 in total
+    int splits;               // split-K factor (EPI_SLAB)
+    const int32_t* a_rows;    // optional row gather for A (M entries), rows >= a_rows_n clamp to entry 0
+    int a_rows_n;
+    // epilogue operands
+    const float* b1;
+    const float* w2;
+    const float* ds;          // dscores, indexed by a_rows[m] (EPI_DH)
+    float* partial;           // EPI_SCORE: [nbn][Mpad]
+    int64_t partial_ld;
+    __bf16* G;                // EPI_DH: [Mpad][N]
+    __bf16* GT;               // EPI_DH: [N][Mpad]
+    int64_t ldgt;
+    float* colpart;           // EPI_DH: [2][nbm][N]  (0: dw2, 1: db1)
+    float* slab;              // EPI_SLAB: [splits][M][N]
+    __bf16* out;              // EPI_ROWS: out[out_rows[m]][n]
+    int64_t ldo;
+    const int32_t* out_rows;
+    int out_rows_n;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every
+    // XCD whole row panels so that all column tiles of a panel hit the same L2.
+    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int per_panel = nbn * p.splits;
+    const int m_tile = (local / per_panel) * 8 + xcd;
+    const int rem = local % per_panel;
+    const int n_tile = rem % nbn;
+    const int split = rem / nbn;
+    if (m_tile >= nbm) return;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int cps = (p.kchunks + p.splits - 1) / p.splits;
+    const int kc0 = split * cps;
+    const int kc1 = min(p.kchunks, kc0 + cps);
+    const int nk = max(0, kc1 - kc0);
+
+    // ---- per-lane staging sources.  Wave w issues 4 A pieces and 4 B pieces per K step; piece i
+    // covers tile rows (w*4+i)*8 .. +8, lane l -> row (l>>3), 16-B chunk (l&7) of the 128-B row.
+    const __bf16* asrc[4];
+    const __bf16* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wid * 4 + i) * 8 + (lane >> 3);
+        const int swz = ((lane >> 4) + 4 * (i & 1)) & 7;       // == (row >> 1) & 7
+        const int chunk = (lane & 7) ^ swz;
+        int am = m0 + row;
+        if (am >= p.M) am = p.M - 1;
+        int64_t arow = am;
+        if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
+        asrc[i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
+        bsrc[i] = p.B + (int64_t)(n0 + row) * p.ldb + (int64_t)kc0 * BK + chunk * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        uint8_t* base = lds + buf * STAGE_BYTES + (wid * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(asrc[i] + (int64_t)kt * BK, base + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(bsrc[i] + (int64_t)kt * BK, base + TILE_BYTES + i * 1024);
+    };
+
+    // fragment read addresses: row r of a tile at r*128, chunk kc stored at position kc ^ ((r>>1)&7)
+    const int frow = lane & 15;
+    const int fswz = frow >> 1;
+    const int fq = lane >> 4;
+
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const uint8_t* At = lds + (kt & 1) * STAGE_BYTES;
+        const uint8_t* Bt = At + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ fswz) << 4;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(At + (wr * 64 + t * 16 + frow) * 128 + coff);
+                bfr[t] = *(const bf16x8*)(Bt + (wc * 64 + t * 16 + frow) * 128 + coff);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // LDS is reused by the epilogues below
+
+    // C layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + j
+    const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
+    float* red = (float*)lds;
+
+    if constexpr (EPI == EPI_SCORE) {
+        float bb[4], ww[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wc * 64 + tn * 16 + ccol;
+            bb[tn] = p.b1[n];
+            ww[tn] = p.w2[n];
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) s += fmaxf(acc[tm][tn][j] + bb[tn], 0.f) * ww[tn];
+                // sum over the 16 lanes that share this row
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                if (ccol == 0) red[(wr * 64 + tm * 16 + crow4 + j) * 2 + wc] = s;
+            }
+        }
+        __syncthreads();
+        if (tid < BM) p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = red[tid * 2] + red[tid * 2 + 1];
+    } else if constexpr (EPI == EPI_DH) {
+        float bb[4], ww[4], c_dw2[4], c_db1[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wc * 64 + tn * 16 + ccol;
+            bb[tn] = p.b1[n];
+            ww[tn] = p.w2[n];
+            c_dw2[tn] = 0.f;
+            c_db1[tn] = 0.f;
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            float dsv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                dsv[j] = (m < p.a_rows_n) ? p.ds[p.a_rows[m]] : 0.f;
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const int n = n0 + wc * 64 + tn * 16 + ccol;
+                bf16x4 gt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float h = acc[tm][tn][j] + bb[tn];
+                    const float g = (h > 0.f) ? dsv[j] * ww[tn] : 0.f;
+                    c_dw2[tn] += dsv[j] * fmaxf(h, 0.f);
+                    c_db1[tn] += g;
+                    const __bf16 gb = (__bf16)g;
+                    gt[j] = gb;
+                    const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                    p.G[(int64_t)m * p.N + n] = gb;
+                }
+                *(bf16x4*)(p.GT + (int64_t)n * p.ldgt + m0 + wr * 64 + tm * 16 + crow4) = gt;
+            }
+        }
+        // column sums over this wave's 64 rows: lanes with equal (lane & 15) hold the same column
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            c_dw2[tn] += __shfl_xor(c_dw2[tn], 16, 64);
+            c_dw2[tn] += __shfl_xor(c_dw2[tn], 32, 64);
+            c_db1[tn] += __shfl_xor(c_db1[tn], 16, 64);
+            c_db1[tn] += __shfl_xor(c_db1[tn], 32, 64);
+            if (lane < 16) {
+                const int c = wc * 64 + tn * 16 + ccol;
+                red[(c * 2 + wr) * 2 + 0] = c_dw2[tn];
+                red[(c * 2 + wr) * 2 + 1] = c_db1[tn];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int64_t o = (int64_t)m_tile * p.N + n0 + tid;
+            p.colpart[o] = red[(tid * 2 + 0) * 2 + 0] + red[(tid * 2 + 1) * 2 + 0];
+            p.colpart[(int64_t)nbm * p.N + o] = red[(tid * 2 + 0) * 2 + 1] + red[(tid * 2 + 1) * 2 + 1];
+        }
+    } else if constexpr (EPI == EPI_SLAB) {
+        float* slab = p.slab + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                    const int n = n0 + wc * 64 + tn * 16 + ccol;
+                    if (m < p.M) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
+                }
+    } else {  // EPI_ROWS
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                if (m >= p.out_rows_n) continue;
+                const int64_t orow = p.out_rows[m];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int n = n0 + wc * 64 + tn * 16 + ccol;
+                    p.out[orow * p.ldo + n] = (__bf16)acc[tm][tn][j];
+                }
+            }
+    }
+}
+
+// scores[m] = b2 + sum over column tiles of partial[t][m]   (fixed order -> reproducible)
+__global__ void scorer_finish_kernel(const float* __restrict__ partial, int64_t ld, int ntiles,
+                                     const float* __restrict__ b2, int64_t N, float* __restrict__ scores) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    float s = b2[0];
+    for (int t = 0; t < ntiles; ++t) s += partial[(int64_t)t * ld + m];
+    scores[m] = s;
+}
+
+// XT[i][r] = X[rows[r]][i] for r < R, 0 for R <= r < Rpad   (bf16, 64x64 tiles through LDS)
+__global__ __launch_bounds__(256) void gather_transpose_kernel(const __bf16* __restrict__ X, int64_t ldx,
+                                                               const int32_t* __restrict__ rows, int R, int Rpad,
+                                                               int d, __bf16* __restrict__ XT) {
+    __shared__ __bf16 tile[64][66];
+    const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int r = r0 + rr;
+        __bf16 v = (__bf16)0.0f;
+        if (r < R) v = X[(int64_t)rows[r] * ldx + i0 + tx];
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 64; ii += 4) {
+        const int r = r0 + tx;
+        if (r < Rpad) XT[(int64_t)(i0 + ii) * Rpad + r] = tile[tx][ii];
+    }
+}
+
+// dst[r][c] = bf16(src[r][c]);  dst_t[c][r] = bf16(src[r][c])
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + tx;
+        float v = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+        tile[rr][tx] = v;
+        if (dst && r < rows && c < cols) dst[(int64_t)r * cols + c] = (__bf16)v;
+    }
+    __syncthreads();
+    if (dst_t)
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc, r = r0 + tx;
+            if (r < rows && c < cols) dst_t[(int64_t)c * rows + r] = (__bf16)tile[tx][cc];
+        }
+}
+
+// dw1 = sum of split-K slabs; db1/dw2 = sum of column partials; db2 = sum of dscores over rows[]
+__global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __restrict__ slab, int splits,
+                                                                int64_t dd, float* __restrict__ dw1,
+                                                                const float* __restrict__ colpart, int nbm, int d,
+                                                                float* __restrict__ dw2, float* __restrict__ db1,
+                                                                const float* __restrict__ ds,
+                                                                const int32_t* __restrict__ rows, int64_t R,
+                                                                float* __restrict__ db2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < dd) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * dd + i];
+        dw1[i] = s;
+    }
+    if (i < d) {
+        float a = 0.f, b = 0.f;
+        for (int t = 0; t < nbm; ++t) {
+            a += colpart[(int64_t)t * d + i];
+            b += colpart[(int64_t)(nbm + t) * d + i];
+        }
+        dw2[i] = a;
+        db1[i] = b;
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        // last block: db2 (fixed-order tree over 256 threads)
+        __shared__ float red[256];
+        float s = 0.f;
+        for (int64_t r = threadIdx.x; r < R; r += 256) s += ds[rows[r]];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) db2[0] = red[0];
+    }
+}
+
+static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
+    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    const int grid = ((nbm + 7) / 8) * 8 * nbn * p.splits;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_done[dev]) {
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_DH>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_done[dev] = true;
+    }
+    switch (epi) {
+        case EPI_SCORE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+    }
+    return 0;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int bwd_splits(int d) {
+    const int tiles = (d / BM) * (d / BN);
+    int s = 512 / tiles;
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+}  // namespace star
+
+extern "C" size_t star_scorer_fwd_workspace(int64_t N, int d) {
+    using namespace star;
+    if (N <= 0 || d <= 0) return 0;
+    return align256((size_t)(d / BN) * (size_t)round_up(N, BM) * sizeof(float));
+}
+
+extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                               int64_t N, int d, float* scores, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    using namespace star;
+    STAR_REQUIRE(x && w1 && b1 && w2 && b2 && scores && workspace, "star_scorer_fwd: null pointer");
+    STAR_REQUIRE(N >= 1 && N < (1ll << 31) - BM, "star_scorer_fwd: bad N=%lld", (long long)N);
+    STAR_REQUIRE(d >= 128 && d % 128 == 0, "star_scorer_fwd: d=%d must be a multiple of 128", d);
+    if (workspace_bytes < star_scorer_fwd_workspace(N, d)) {
+        set_error("star_scorer_fwd: workspace %zu < %zu bytes", workspace_bytes, star_scorer_fwd_workspace(N, d));
+        return STAR_ERR_WORKSPACE;
+    }
+    GemmParams p = {};
+    p.A = (const __bf16*)x;
+    p.B = (const __bf16*)w1;
+    p.lda = d;
+    p.ldb = d;
+    p.M = (int)N;
+    p.N = d;
+    p.kchunks = d / BK;
+    p.splits = 1;
+    p.b1 = b1;
+    p.w2 = w2;
+    p.partial = (float*)workspace;
+    p.partial_ld = round_up(N, BM);
+    hipStream_t st = (hipStream_t)stream;
+    launch_gemm(EPI_SCORE, p, st);
+    hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
+                       p.partial_ld, d / BN, b2, N, scores);
+    STAR_LAUNCH_CHECK("star_scorer_fwd");
+    return STAR_OK;
+}
+
+extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
+    using namespace star;
+    if (R <= 0 || d <= 0) return 0;
+    const int64_t Rpad = round_up(R, BM);
+    const int nbm = (int)(Rpad / BM);
+    size_t g = align256((size_t)Rpad * d * 2);
+    return 3 * g + align256((size_t)2 * nbm * d * 4) + align256((size_t)bwd_splits(d) * d * d * 4);
+}
+
+extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1, const float* w2,
+                               const float* dscores, const int32_t* rows, int64_t R, int64_t N, int d, float* dw1,
+                               float* db1, float* dw2, float* db2, void* dx, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    using namespace star;
+    STAR_REQUIRE(x && w1 && b1 && w2 && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
+                 "star_scorer_bwd: null pointer");
+    STAR_REQUIRE(!dx || w1t, "star_scorer_bwd: dx requested without w1t");
+    STAR_REQUIRE(R >= 1 && R <= N && N < (1ll << 31) - BM, "star_scorer_bwd: bad R=%lld N=%lld", (long long)R, (long long)N);
+    STAR_REQUIRE(d >= 128 && d % 128 == 0, "star_scorer_bwd: d=%d must be a multiple of 128", d);
+    if (workspace_bytes < star_scorer_bwd_workspace(R, d)) {
+        set_error("star_scorer_bwd: workspace %zu < %zu bytes", workspace_bytes, star_scorer_bwd_workspace(R, d));
+        return STAR_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t Rpad = round_up(R, BM);
+    const int nbm = (int)(Rpad / BM);
+    const int splits = bwd_splits(d);
+    uint8_t* ws = (uint8_t*)workspace;
+    const size_t gbytes = align256((size_t)Rpad * d * 2);
+    __bf16* G = (__bf16*)ws;
+    __bf16* GT = (__bf16*)(ws + gbytes);
+    __bf16* XT = (__bf16*)(ws + 2 * gbytes);
+    float* colpart = (float*)(ws + 3 * gbytes);
+    float* slab = (float*)(ws + 3 * gbytes + align256((size_t)2 * nbm * d * 4));
+
+    // 1. recompute H for the listed rows, emit G = dH and G^T, column partials for dw2 / db1
+    GemmParams p = {};
+    p.A = (const __bf16*)x;
+    p.B = (const __bf16*)w1;
+    p.lda = d;
+    p.ldb = d;
+    p.M = (int)Rpad;
+    p.N = d;
+    p.kchunks = d / BK;
+    p.splits = 1;
+    p.a_rows = rows;
+    p.a_rows_n = (int)R;
+    p.b1 = b1;
+    p.w2 = w2;
+    p.ds = dscores;
+    p.G = G;
+    p.GT = GT;
+    p.ldgt = Rpad;
+    p.colpart = colpart;
+    launch_gemm(EPI_DH, p, st);
+    // 2. X_sel^T
+    hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, st,
+                       (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
+    // 3. dW1 = G^T . X_sel  (split-K slabs)
+    GemmParams q = {};
+    q.A = GT;
+    q.B = XT;
+    q.lda = Rpad;
+    q.ldb = Rpad;
+    q.M = d;
+    q.N = d;
+    q.kchunks = (int)(Rpad / BK);
+    q.splits = splits;
+    q.slab = slab;
+    launch_gemm(EPI_SLAB, q, st);
+    // 4. reductions
+    const int64_t dd = (int64_t)d * d;
+    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(cdiv(dd, 256)), dim3(256), 0, st, (const float*)slab, splits, dd,
+                       dw1, (const float*)colpart, nbm, d, dw2, db1, dscores, rows, R, db2);
+    // 5. dX rows = G . W1
+    if (dx) {
+        GemmParams r = {};
+        r.A = G;
+        r.B = (const __bf16*)w1t;
+        r.lda = d;
+        r.ldb = d;
+        r.M = (int)Rpad;
+        r.N = d;
+        r.kchunks = d / BK;
+        r.splits = 1;
+        r.out = (__bf16*)dx;
+        r.ldo = d;
+        r.out_rows = rows;
+        r.out_rows_n = (int)R;
+        launch_gemm(EPI_ROWS, r, st);
+    }
+    STAR_LAUNCH_CHECK("star_scorer_bwd");
+    return STAR_OK;
+}
+
+extern "C" int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(src && (dst || dst_t), "star_cast_transpose_bf16: null pointer");
+    STAR_REQUIRE(rows >= 1 && cols >= 1, "star_cast_transpose_bf16: bad shape %d x %d", rows, cols);
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(cols, 64), cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       src, rows, cols, (__bf16*)dst, (__bf16*)dst_t);
+    STAR_LAUNCH_CHECK("star_cast_transpose_bf16");
+    return STAR_OK;
+}

@@ -1,0 +1,224 @@
+"""Drop-in mirror of the reference's nugget operators (same names, arguments and return values).
+
+The reference has no plugin interface; its boundary is these Python signatures:
+
+  reference (src/models/...)                               here
+  -------------------------------------------------------  ------------------------------------------
+  nugget_model = Sequential(Linear, ReLU, Linear)          NuggetScorer                (w2v_asr.py:113-117)
+  W2VASRModel.apply_nugget_compression (w2v_asr.py:208)    NuggetOpsMixin.apply_nugget_compression
+  W2VASRModel.add_nugget_type_embedding (w2v_asr.py:316)   NuggetOpsMixin.add_nugget_type_embedding
+  W2VSimulModel.resize (w2v_simul.py:504)                  NuggetOpsMixin.resize
+  W2VSimulModel.apply_threshold_yield_nugget (:376)        NuggetOpsMixin.apply_threshold_yield_nugget
+  W2VSimulModel.get_valid_mask_indices (:196)              NuggetOpsMixin.get_valid_mask_indices
+  semantic_repr[arange(B)[:,None], nugget_indices]         gather_nuggets              (w2v_asr.py:566-567)
+  MyGPT2Attention._attn (my_transformer.py:535)            score_biased_attn / NuggetCrossAttention._attn
+  MyGPT2Attention.forward, cross branch (:490-533)         NuggetCrossAttention.forward
+
+A maintainer of the reference makes `W2VASRModel` / `W2VSimulModel` inherit `NuggetOpsMixin` (first in
+the MRO), builds `self.nugget_model = NuggetScorer(hidden_size)` and uses `NuggetCrossAttention` for
+`MyGPT2Block.crossattention`; parameter names (`nugget_model.0.weight`, `crossattention.c_attn.weight`,
+...) are unchanged, so checkpoints and the trainers' optimizer grouping keep working.
+Everything runs in the HIP kernels of libstar_nugget.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------ a1
+class NuggetScorer(nn.Sequential):
+    """nn.Sequential(nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, 1)) with a fused HIP forward/backward.
+    state_dict keys: 0.weight, 0.bias, 2.weight, 2.bias -- identical to the reference module."""
+
+    def __init__(self, hidden_size: int):
+        super().__init__(nn.Linear(hidden_size, hidden_size), nn.ReLU(inplace=True), nn.Linear(hidden_size, 1))
+        self.active_rows = ops.ActiveRows()
+
+    def set_active_rows(self, rows: Optional[torch.Tensor]):
+        """Optional: frames (flattened b*T+t) that can receive a score gradient this step (None = all)."""
+        self.active_rows.rows = rows
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,T,d] -> [B,T,1]
+        s = ops.scorer(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias, self.active_rows)
+        return s.to(x.dtype if x.dtype != torch.bfloat16 else torch.float32).unsqueeze(-1)
+
+
+# ------------------------------------------------------------------------------------------ a4
+def gather_nuggets(semantic_repr: torch.Tensor, nugget_indices: torch.Tensor) -> torch.Tensor:
+    """semantic_repr[torch.arange(B)[:, None], nugget_indices]; -1 indexes the last frame, as in the reference."""
+    return ops.gather_rows(semantic_repr, nugget_indices)
+
+
+# ------------------------------------------------------------------------------------------ a2, a3, a6, a7
+class NuggetOpsMixin:
+    """Methods with the reference's names and signatures; expects `self.nugget_compress_rate` and
+    `self.nugget_model` like the reference classes."""
+
+    def apply_nugget_compression(self, encoder_repr, attn_mask, nugget_scores=None, n_nugget=None):
+        """-> (nugget_mask [B,K] bool, indices_ascending [B,K] int64, scores_gather [B,K])  (w2v_asr.py:208-244).
+        Like the reference this reads max(k_b) back to the host to size the outputs."""
+        if nugget_scores is None:
+            nugget_scores = self.nugget_model(encoder_repr).squeeze(-1)
+        rate = None if n_nugget is not None else self.nugget_compress_rate
+        nmask, idx, sg = ops.topk_select(nugget_scores, attn_mask=attn_mask, rate=rate, n_nugget=n_nugget,
+                                         want_table=False)
+        return nmask, idx, sg
+
+    @staticmethod
+    def add_nugget_type_embedding(inputs_embed, nugget_indices, nugget_mask):
+        """-> (type_ind_table [B,T] int64, nugget_position [B,K] int64 with pads = -1)  (w2v_asr.py:316-323).
+        The fused path (`select_nuggets`) gets both from the select kernel for free."""
+        return ops.type_table(nugget_indices, nugget_mask, inputs_embed.shape[1])
+
+    def select_nuggets(self, nugget_scores, attn_mask=None, lengths=None, K: Optional[int] = None):
+        """Fused apply_nugget_compression + add_nugget_type_embedding: one kernel, no host sync when K is given.
+        -> (nugget_mask, indices_ascending, scores_gather, type_ind_table, nugget_position)."""
+        return ops.topk_select(nugget_scores, attn_mask=attn_mask, lengths=lengths,
+                               rate=self.nugget_compress_rate, K=K, want_table=True)
+
+    def resize(self, alphas, target_lengths, noise=0.0, threshold=1.0):
+        """w2v_simul.py:504-535.  noise must be 0 (the only value the reference ever passes)."""
+        if noise != 0.0:
+            raise NotImplementedError("resize: noise != 0 is never used by the reference and is not implemented")
+        return ops.cif_resize(alphas, target_lengths, threshold=threshold)
+
+    @staticmethod
+    def get_valid_mask_indices(mask: torch.Tensor, padding_value: int = -1):
+        """w2v_simul.py:196-220: ascending positions of the True entries, padded; -> (indices, max_valid, n)."""
+        assert len(mask.shape) <= 2, f"Only supports 1D or 2D tensors - got {len(mask.shape)}."
+        m2 = mask if mask.dim() == 2 else mask.unsqueeze(0)
+        # a fire scan over a 0/1 "alpha" fires exactly at the True positions
+        # (lengths = T+1: every frame counts, and the forced last-frame fire never triggers)
+        idx, _, counts, mx, _ = ops.cif_fire_scan(m2.to(torch.float32), lengths=torch.full(
+            (m2.shape[0],), m2.shape[1] + 1, dtype=torch.int32, device=m2.device))
+        max_valid = int(mx.item())
+        idx = idx[:, :max_valid]
+        if padding_value != -1:
+            idx = torch.where(idx < 0, torch.full_like(idx, padding_value), idx)
+        if mask.dim() == 1:
+            idx = idx[0]
+        return idx, max_valid, counts.to(torch.int64) if mask.dim() == 2 else counts.to(torch.int64)[0]
+
+    def apply_threshold_yield_nugget(self, alphas, attn_mask, build_block_mask: bool = True):
+        """-> (nugget_mask [B,Kf] bool, nugget_indices [B,Kf] int64 (-1 padded), block_attn_mask [B,T,T] fp32)
+        (w2v_simul.py:376-403).  One device->host read of the fire count sizes the outputs (the reference
+        does the same through `.item()`).  The [B,T,T] block mask is unused by the live model
+        (`use_soft = False`, w2v_simul.py:440-444): pass build_block_mask=False to skip its T*T*B*4 bytes."""
+        idx, nmask, counts, mx, _ = ops.cif_fire_scan(alphas, attn_mask=attn_mask)
+        kf = int(mx.item())
+        block = None
+        if build_block_mask:
+            block = ops.cif_block_mask(idx, counts, attn_mask=attn_mask)
+        return nmask[:, :kf], idx[:, :kf], block
+
+
+# ------------------------------------------------------------------------------------------ a8
+def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
+                      limit_cross_attn=False, scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
+                      layer_idx=0, key_lengths=None, output_attentions=False):
+    """MyGPT2Attention._attn for cross-attention (my_transformer.py:535-603), dropout p = 0.
+
+    query [B,h,L,hd], key/value [B,h,K,hd]; attention_mask is the additive [B,1,1,K] encoder mask produced
+    by invert_attention_mask (0 / finfo.min); scorer_logits [B,Kb<=K].  Returns (attn_output, attn_weights or
+    None).  The additive mask and the scorer logits are folded into one per-key bias vector, which is what the
+    kernel consumes; `key_lengths` (optional, [B]) lets the kernel skip fully padded key tiles."""
+    if head_mask is not None:
+        raise NotImplementedError("head_mask is always None on the reference path (get_head_mask of [None]*n_layer)")
+    scale = 1.0
+    if scale_attn_weights:
+        scale = scale / (value.size(-1) ** 0.5)
+    if scale_attn_by_inverse_layer_idx:
+        scale = scale / float(layer_idx + 1)
+    bias = None
+    B, K = query.shape[0], key.shape[2]
+    if attention_mask is not None:
+        if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
+            raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
+        bias = attention_mask.reshape(B, K).to(torch.float32)
+    if scorer_logits is not None:
+        s = scorer_logits.to(torch.float32)
+        if s.shape[1] > K:
+            raise ValueError(f"scorer_logits has {s.shape[1]} columns but there are only {K} keys")
+        if s.shape[1] < K:   # prefix-bias variant (my_transformer.py:114-125): zero-extend
+            s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
+        bias = s if bias is None else bias + s
+    out, probs = ops.xattn(query, key, value, bias=bias, key_len=key_lengths,
+                           ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions)
+    return out, probs
+
+
+class Conv1D(nn.Module):
+    """HF GPT-2's Conv1D (transformers 4.34 pytorch_utils.Conv1D): y = x @ weight + bias, weight [in, out]."""
+
+    def __init__(self, nf: int, nx: int):
+        super().__init__()
+        self.nf = nf
+        self.weight = nn.Parameter(torch.empty(nx, nf))
+        self.bias = nn.Parameter(torch.zeros(nf))
+        nn.init.normal_(self.weight, std=0.02)
+
+    def forward(self, x):
+        size_out = x.size()[:-1] + (self.nf,)
+        x = torch.addmm(self.bias, x.view(-1, x.size(-1)), self.weight)
+        return x.view(size_out)
+
+
+class NuggetCrossAttention(nn.Module):
+    """Cross-attention branch of MyGPT2Attention.forward (my_transformer.py:490-533) with the fused core.
+    Parameters: q_attn, c_attn, c_proj (Conv1D layout) as in GPT2Attention(is_cross_attention=True)."""
+
+    def __init__(self, hidden_size: int, num_heads: int, layer_idx: int = 0, scale_attn_weights: bool = True,
+                 scale_attn_by_inverse_layer_idx: bool = False, resid_pdrop: float = 0.0):
+        super().__init__()
+        if hidden_size % num_heads:
+            raise ValueError("`embed_dim` must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.head_dim = hidden_size, num_heads, hidden_size // num_heads
+        self.split_size = hidden_size
+        self.layer_idx = layer_idx
+        self.scale_attn_weights = scale_attn_weights
+        self.scale_attn_by_inverse_layer_idx = scale_attn_by_inverse_layer_idx
+        self.is_cross_attention = True
+        self.c_attn = Conv1D(2 * hidden_size, hidden_size)
+        self.q_attn = Conv1D(hidden_size, hidden_size)
+        self.c_proj = Conv1D(hidden_size, hidden_size)
+        self.resid_dropout = nn.Dropout(resid_pdrop)
+
+    def _split_heads(self, t):
+        return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).permute(0, 2, 1, 3)
+
+    def _attn(self, query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
+              limit_cross_attn=False, output_attentions=False):
+        return score_biased_attn(query, key, value, attention_mask, head_mask, scorer_logits, limit_cross_attn,
+                                 self.scale_attn_weights, self.scale_attn_by_inverse_layer_idx, self.layer_idx,
+                                 output_attentions=output_attentions)
+
+    def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, use_cache=False, output_attentions=False,
+                scorer_logits=None, limit_cross_attn=False):
+        if encoder_hidden_states is None:
+            raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
+        query = self._split_heads(self.q_attn(hidden_states))
+        key, value = self.c_attn(encoder_hidden_states).split(self.split_size, dim=2)
+        key, value = self._split_heads(key), self._split_heads(value)
+        if layer_past is not None:
+            past_key, past_value = layer_past
+            key = torch.cat((past_key, key), dim=-2)
+            value = torch.cat((past_value, value), dim=-2)
+        present = (key, value) if use_cache else None
+        attn_output, attn_weights = self._attn(query, key, value, encoder_attention_mask, head_mask, scorer_logits,
+                                               limit_cross_attn=bool(limit_cross_attn),
+                                               output_attentions=output_attentions)
+        # merge heads: the kernel already wrote [B, L, h, hd] memory order
+        b, h, l, hd = attn_output.shape
+        attn_output = attn_output.permute(0, 2, 1, 3).reshape(b, l, h * hd)
+        attn_output = self.resid_dropout(self.c_proj(attn_output))
+        outputs = (attn_output, present)
+        if output_attentions:
+            outputs += (attn_weights,)
+        return outputs

@@ -1,0 +1,421 @@
+"""Operator layer: torch tensors in, HIP kernels (through the C ABI) out.
+
+Every function here launches kernels from libstar_nugget.so on the current torch stream.  torch is
+used for device memory, streams and autograd bookkeeping only.  Reference citations are relative to
+the STAR checkout (src/models/...).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import XAttnShape, check, lib, ptr, stream_ptr
+
+DT_BF16, DT_F32 = 0, 1
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise StarDeviceError("star_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+class StarDeviceError(RuntimeError):
+    pass
+
+
+def _mask_or_lengths(attn_mask, lengths):
+    """Returns (mask_u8 or None, lengths_i32 or None): exactly one is set."""
+    if (attn_mask is None) == (lengths is None):
+        raise ValueError("give exactly one of attn_mask / lengths")
+    if attn_mask is not None:
+        m = attn_mask
+        if m.dtype != torch.bool and m.dtype != torch.uint8:
+            m = m != 0
+        m = m.contiguous()
+        return m.view(torch.uint8) if m.dtype == torch.bool else m, None
+    return None, lengths.to(torch.int32).contiguous()
+
+
+# ----------------------------------------------------------------------------- a2 + a3
+def nugget_counts_host(n_tok, rate: float) -> np.ndarray:
+    """k_b = trunc(fp32(n_tok) * fp32(1/rate) + 0.99) clamped to n_tok (w2v_asr.py:219-221), on the host
+    (used only to size the outputs; the kernel recomputes k_b itself)."""
+    n = np.asarray(n_tok, dtype=np.int64)
+    k = (n.astype(np.float32) * np.float32(1.0 / rate)).astype(np.float32) + np.float32(0.99)
+    return np.minimum(k.astype(np.float32).astype(np.int64), n)
+
+
+class _TopkSelect(torch.autograd.Function):
+    """apply_nugget_compression + add_nugget_type_embedding (w2v_asr.py:208-244, 316-323) in one kernel.
+    Differentiable only through scores_gather (w2v_asr.py:243)."""
+
+    @staticmethod
+    def forward(ctx, scores, mask_u8, lengths_i32, n_nugget_i32, ratio, K, want_table):
+        B, T = scores.shape
+        dev = scores.device
+        s = scores.detach().to(torch.float32).contiguous()
+        idx = torch.empty((B, K), dtype=torch.int64, device=dev)
+        nmask = torch.empty((B, K), dtype=torch.uint8, device=dev)
+        sg = torch.empty((B, K), dtype=torch.float32, device=dev)
+        table = torch.empty((B, T), dtype=torch.int64, device=dev) if want_table else None
+        pos = torch.empty((B, K), dtype=torch.int64, device=dev) if want_table else None
+        check(lib().star_topk_select(ptr(s), ptr(mask_u8), ptr(lengths_i32), ptr(n_nugget_i32), float(ratio),
+                                     B, T, K, ptr(idx), ptr(nmask), ptr(sg), ptr(table), ptr(pos), stream_ptr()),
+              "star_topk_select")
+        ctx.save_for_backward(idx)
+        ctx.T = T
+        ctx.in_dtype = scores.dtype
+        nmask = nmask.view(torch.bool)
+        ctx.mark_non_differentiable(idx, nmask)
+        if want_table:
+            ctx.mark_non_differentiable(table, pos)
+            return nmask, idx, sg.to(scores.dtype), table, pos
+        return nmask, idx, sg.to(scores.dtype)
+
+    @staticmethod
+    def backward(ctx, g_mask, g_idx, g_sg, *rest):
+        (idx,) = ctx.saved_tensors
+        B, K = idx.shape
+        g = g_sg.to(torch.float32).contiguous()
+        ds = torch.empty((B, ctx.T), dtype=torch.float32, device=g.device)
+        check(lib().star_gather_rows_bwd(ptr(g), ptr(idx), ptr(ds), B, ctx.T, K, 1, DT_F32, stream_ptr()),
+              "star_gather_rows_bwd")
+        return ds.to(ctx.in_dtype), None, None, None, None, None, None
+
+
+def topk_select(scores, attn_mask=None, lengths=None, rate: Optional[float] = None, n_nugget=None,
+                K: Optional[int] = None, want_table: bool = True):
+    """Top-k anchor selection.  `K` (= max_b k_b) may be passed to avoid a device->host sync; when it is
+    None it is derived from the lengths exactly like the reference (w2v_asr.py:227: `n_nugget.max()`),
+    which costs one small readback."""
+    _need_cuda(scores, attn_mask, lengths, n_nugget)
+    mask_u8, lengths_i32 = _mask_or_lengths(attn_mask, lengths)
+    nn_i32 = None if n_nugget is None else n_nugget.to(torch.int32).contiguous()
+    if nn_i32 is None and rate is None:
+        raise ValueError("need rate or n_nugget")
+    ratio = 0.0 if rate is None else float(np.float32(1.0 / rate))
+    if K is None:
+        if nn_i32 is not None:
+            K = int(nn_i32.max().item())
+        else:
+            n_tok = mask_u8.sum(dim=1) if mask_u8 is not None else lengths_i32
+            K = int(nugget_counts_host(n_tok.cpu().numpy(), rate).max())
+    return _TopkSelect.apply(scores, mask_u8, lengths_i32, nn_i32, ratio, int(K), want_table)
+
+
+def type_table(nugget_indices, nugget_mask, T: int):
+    """add_nugget_type_embedding (w2v_asr.py:316-323): -> (table [B,T] int64, positions [B,K] int64)."""
+    _need_cuda(nugget_indices, nugget_mask)
+    idx = nugget_indices.to(torch.int64).contiguous()
+    m = nugget_mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else (m != 0).view(torch.uint8)
+    B, K = idx.shape
+    table = torch.empty((B, T), dtype=torch.int64, device=idx.device)
+    pos = torch.empty((B, K), dtype=torch.int64, device=idx.device)
+    check(lib().star_nugget_type_table(ptr(idx), ptr(m), B, T, K, ptr(table), ptr(pos), stream_ptr()),
+          "star_nugget_type_table")
+    return table, pos
+
+
+# ----------------------------------------------------------------------------- a4
+class _GatherRows(torch.autograd.Function):
+    """semantic_repr[arange(B)[:,None], nugget_indices] (w2v_asr.py:566-567, w2v_simul.py:427,446-447)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        squeeze = src.dim() == 2
+        s3 = src.unsqueeze(-1) if squeeze else src
+        s3 = s3.contiguous()
+        B, T, d = s3.shape
+        K = idx.shape[1]
+        idx = idx.contiguous()
+        out = torch.empty((B, K, d), dtype=s3.dtype, device=s3.device)
+        check(lib().star_gather_rows_fwd(ptr(s3), ptr(idx), ptr(out), B, T, K, d * s3.element_size(), stream_ptr()),
+              "star_gather_rows_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, T, d)
+        ctx.squeeze = squeeze
+        return out.squeeze(-1) if squeeze else out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, T, d = ctx.shape
+        K = idx.shape[1]
+        if g.dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError(f"gather_rows backward supports bf16/fp32, got {g.dtype}")
+        g3 = (g.unsqueeze(-1) if ctx.squeeze else g).contiguous()
+        ds = torch.empty((B, T, d), dtype=g.dtype, device=g.device)
+        check(lib().star_gather_rows_bwd(ptr(g3), ptr(idx), ptr(ds), B, T, K, d,
+                                         DT_BF16 if g.dtype == torch.bfloat16 else DT_F32, stream_ptr()),
+              "star_gather_rows_bwd")
+        return (ds.squeeze(-1) if ctx.squeeze else ds), None
+
+
+def gather_rows(src, idx):
+    """dst[b,j] = src[b, idx[b,j]] for src [B,T,d] or [B,T]; idx -1 addresses the last frame."""
+    _need_cuda(src, idx)
+    if src.dtype not in (torch.bfloat16, torch.float32, torch.float16):
+        raise TypeError(f"gather_rows: unsupported dtype {src.dtype}")
+    return _GatherRows.apply(src, idx.to(torch.int64))
+
+
+# ----------------------------------------------------------------------------- a5
+class _CifQuantity(torch.autograd.Function):
+    """alphas = sigmoid(scores)*mask; loss = mean((sum alphas/thr - L)^2)  (w2v_simul.py:419-424)."""
+
+    @staticmethod
+    def forward(ctx, scores, mask_u8, lengths_i32, target_i32, threshold):
+        B, T = scores.shape
+        s = scores.detach().to(torch.float32).contiguous()
+        alphas = torch.empty_like(s)
+        diff = torch.empty((B,), dtype=torch.float32, device=s.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=s.device)
+        check(lib().star_cif_quantity_fwd(ptr(s), ptr(mask_u8), ptr(lengths_i32), ptr(target_i32), float(threshold),
+                                          B, T, ptr(alphas), ptr(diff), ptr(loss), stream_ptr()),
+              "star_cif_quantity_fwd")
+        ctx.save_for_backward(alphas, diff)
+        ctx.threshold = float(threshold)
+        ctx.in_dtype = scores.dtype
+        ctx.mark_non_differentiable(alphas)
+        return alphas, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_alphas, g_loss):
+        alphas, diff = ctx.saved_tensors
+        B, T = alphas.shape
+        gl = g_loss.to(torch.float32).reshape(1).contiguous()
+        ds = torch.empty_like(alphas)
+        check(lib().star_cif_quantity_bwd(ptr(alphas), ptr(diff), ptr(gl), ctx.threshold, B, T, 0, ptr(ds),
+                                          stream_ptr()), "star_cif_quantity_bwd")
+        return ds.to(ctx.in_dtype), None, None, None, None
+
+
+def cif_quantity(scores, target_lengths, attn_mask=None, lengths=None, threshold: float = 1.0):
+    """Returns (alphas [B,T] fp32 (detached, as the live reference path only uses it detached), loss scalar)."""
+    _need_cuda(scores, target_lengths, attn_mask, lengths)
+    mask_u8, lengths_i32 = _mask_or_lengths(attn_mask, lengths)
+    return _CifQuantity.apply(scores, mask_u8, lengths_i32, target_lengths.to(torch.int32).contiguous(), threshold)
+
+
+# ----------------------------------------------------------------------------- a6
+def cif_resize(alphas, target_lengths, threshold: float = 1.0, max_rounds: int = 10):
+    """W2VSimulModel.resize (w2v_simul.py:504-535), noise = 0.  No gradient (the live call site detaches it)."""
+    _need_cuda(alphas, target_lengths)
+    a = alphas.detach().to(torch.float32).contiguous()
+    B, T = a.shape
+    out = torch.empty_like(a)
+    check(lib().star_cif_resize(ptr(a), ptr(target_lengths.to(torch.int32).contiguous()), float(threshold),
+                                int(max_rounds), B, T, ptr(out), stream_ptr()), "star_cif_resize")
+    return out
+
+
+# ----------------------------------------------------------------------------- a7
+def cif_fire_scan(alphas, attn_mask=None, lengths=None, cap: Optional[int] = None, scores=None):
+    """apply_threshold_yield_nugget's scan (w2v_simul.py:376-403).  Returns
+    (idx [B,cap] int64 -1 padded, mask [B,cap] bool, counts [B] int32, max_count [1] int32, scores_gather or None).
+    No host sync happens here; `cap` defaults to T."""
+    _need_cuda(alphas, attn_mask, lengths, scores)
+    mask_u8, lengths_i32 = _mask_or_lengths(attn_mask, lengths)
+    a = alphas.detach().to(torch.float32).contiguous()
+    B, T = a.shape
+    cap = T if cap is None else int(cap)
+    dev = a.device
+    idx = torch.empty((B, cap), dtype=torch.int64, device=dev)
+    m = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    mx = torch.empty((1,), dtype=torch.int32, device=dev)
+    sc = sg = None
+    if scores is not None:
+        sc = scores.detach().to(torch.float32).contiguous()
+        sg = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    check(lib().star_cif_fire_scan(ptr(a), ptr(mask_u8), ptr(lengths_i32), ptr(sc), B, T, cap, ptr(idx), ptr(m),
+                                   ptr(counts), ptr(mx), ptr(sg), stream_ptr()), "star_cif_fire_scan")
+    return idx, m.view(torch.bool), counts, mx, sg
+
+
+def cif_block_mask(idx, counts, attn_mask=None, lengths=None, T: Optional[int] = None):
+    """block_attn_mask [B,T,T] fp32 (w2v_simul.py:382-402), built on demand from the fire positions."""
+    _need_cuda(idx, counts, attn_mask, lengths)
+    mask_u8, lengths_i32 = _mask_or_lengths(attn_mask, lengths)
+    B, cap = idx.shape
+    if T is None:
+        T = mask_u8.shape[1]
+    out = torch.empty((B, T, T), dtype=torch.float32, device=idx.device)
+    check(lib().star_cif_block_mask(ptr(idx.contiguous()), ptr(counts), ptr(mask_u8), ptr(lengths_i32), B, T, cap,
+                                    ptr(out), stream_ptr()), "star_cif_block_mask")
+    return out
+
+
+# ----------------------------------------------------------------------------- a1
+class ActiveRows:
+    """Mutable hint shared between the scorer and the selector: the frames (flattened b*T+t, int32) whose
+    dscore can be non-zero.  In the non-streaming path only the <= K selected frames per utterance get a
+    gradient (loss = lm_loss only, w2v_asr.py:580-581), so the scorer backward runs on those rows alone.
+    Leave .rows = None for a dense backward."""
+
+    def __init__(self):
+        self.rows = None
+
+
+class _Scorer(torch.autograd.Function):
+    """scores = w2 . relu(W1 x + b1) + b2 (w2v_asr.py:113-117,553); bf16 MFMA, fp32 accumulate/scores."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, hint):
+        d = x.shape[-1]
+        xb = x.detach()
+        if xb.dtype != torch.bfloat16:
+            xb = xb.to(torch.bfloat16)
+        xb = xb.contiguous().view(-1, d)
+        N = xb.shape[0]
+        dev = xb.device
+        w1f = w1.detach().to(torch.float32).contiguous()
+        w1b = torch.empty((d, d), dtype=torch.bfloat16, device=dev)
+        w1t = torch.empty((d, d), dtype=torch.bfloat16, device=dev)
+        check(lib().star_cast_transpose_bf16(ptr(w1f), d, d, ptr(w1b), ptr(w1t), stream_ptr()),
+              "star_cast_transpose_bf16")
+        b1f = b1.detach().to(torch.float32).contiguous()
+        w2f = w2.detach().to(torch.float32).contiguous().view(-1)
+        b2f = b2.detach().to(torch.float32).contiguous().view(-1)
+        wsb = lib().star_scorer_fwd_workspace(N, d)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        scores = torch.empty((N,), dtype=torch.float32, device=dev)
+        check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(ws),
+                                    wsb, stream_ptr()), "star_scorer_fwd")
+        ctx.save_for_backward(xb, w1b, w1t, b1f, w2f)
+        ctx.hint = hint
+        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
+        ctx.w_dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.w2_shape = w2.shape
+        ctx.b2_shape = b2.shape
+        return scores.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, w1b, w1t, b1f, w2f = ctx.saved_tensors
+        N, d = xb.shape
+        dev = xb.device
+        ds = g.to(torch.float32).contiguous().view(-1)
+        rows = ctx.hint.rows if ctx.hint is not None else None
+        if rows is None:
+            rows = torch.arange(N, dtype=torch.int32, device=dev)
+        rows = rows.to(torch.int32).contiguous().view(-1)
+        R = rows.numel()
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.zeros((N, d), dtype=torch.bfloat16, device=dev) if need_dx else None
+        dw1 = torch.empty((d, d), dtype=torch.float32, device=dev)
+        db1 = torch.empty((d,), dtype=torch.float32, device=dev)
+        dw2 = torch.empty((d,), dtype=torch.float32, device=dev)
+        db2 = torch.empty((1,), dtype=torch.float32, device=dev)
+        wsb = lib().star_scorer_bwd_workspace(R, d)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1t), ptr(b1f), ptr(w2f), ptr(ds), ptr(rows), R, N, d,
+                                    ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), ptr(ws), wsb, stream_ptr()),
+              "star_scorer_bwd")
+        t1, t2, t3, t4 = ctx.w_dtypes
+        gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
+        return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None)
+
+
+def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None):
+    """x [..., d] -> scores [...] fp32.  w1 [d,d] (nn.Linear layout), b1 [d], w2 [1,d], b2 [1]."""
+    _need_cuda(x, w1, b1, w2, b2)
+    return _Scorer.apply(x, w1, b1, w2, b2, hint)
+
+
+# ----------------------------------------------------------------------------- a8
+def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale):
+    B, h, L, hd = q.shape
+    Kn = k.shape[2]
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        if t.stride(-1) != 1:
+            raise ValueError(f"xattn: {name} must have a contiguous head dimension")
+        if t.data_ptr() % 16:
+            raise ValueError(f"xattn: {name} must be 16-byte aligned")
+    s = XAttnShape()
+    s.B, s.h, s.L, s.Kn, s.hd = B, h, L, Kn, hd
+    s.q_sb, s.q_sh, s.q_sr = q.stride(0), q.stride(1), q.stride(2)
+    s.k_sb, s.k_sh, s.k_sr = k.stride(0), k.stride(1), k.stride(2)
+    s.v_sb, s.v_sh, s.v_sr = v.stride(0), v.stride(1), v.stride(2)
+    s.o_sb, s.o_sh, s.o_sr = o.stride(0), o.stride(1), o.stride(2)
+    s.bias_len, s.ilk_diag, s.scale = int(bias_len), int(ilk_diag), float(scale)
+    return s
+
+
+class _XAttn(torch.autograd.Function):
+    """softmax(QK^T*scale + ILK + bias) V with d(bias) = sum_{h,i} dS (my_transformer.py:535-603)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs):
+        in_dtype = q.dtype
+        qb, kb, vb = (t.detach() if t.dtype == torch.bfloat16 else t.detach().to(torch.bfloat16) for t in (q, k, v))
+        B, h, L, hd = qb.shape
+        dev = qb.device
+        # output in [B, L, h, hd] memory order (what merge_heads wants), exposed as [B,h,L,hd]
+        o = torch.empty((B, L, h, hd), dtype=torch.bfloat16, device=dev).permute(0, 2, 1, 3)
+        lse = torch.empty((B, h, L), dtype=torch.float32, device=dev)
+        bias_f = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        bias_len = 0 if bias_f is None else bias_f.shape[1]
+        kl = None if key_len is None else key_len.to(torch.int32).contiguous()
+        probs = torch.empty((B, h, L, kb.shape[2]), dtype=torch.float32, device=dev) if need_probs else None
+        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
+        check(lib().star_xattn_fwd(ptr(qb), ptr(kb), ptr(vb), ptr(bias_f), ptr(kl), s, ptr(o), ptr(lse), ptr(probs),
+                                   stream_ptr()), "star_xattn_fwd")
+        ctx.save_for_backward(qb, kb, vb, o, lse, bias_f, kl)
+        ctx.cfg = (ilk_diag, scale, bias_len)
+        ctx.in_dtype = in_dtype
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        out = o if in_dtype == torch.bfloat16 else o.to(in_dtype)
+        if need_probs:
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out, None
+
+    @staticmethod
+    def backward(ctx, g, g_probs):
+        qb, kb, vb, o, lse, bias_f, kl = ctx.saved_tensors
+        ilk_diag, scale, bias_len = ctx.cfg
+        B, h, L, hd = qb.shape
+        Kn = kb.shape[2]
+        dev = qb.device
+        # dO must share o's strides
+        go = torch.empty_like(o)
+        go.copy_(g)
+        dq = torch.empty_like(qb)
+        dk = torch.empty_like(kb)
+        dv = torch.empty_like(vb)
+        if dq.stride() != qb.stride() or dk.stride() != kb.stride() or dv.stride() != vb.stride():
+            raise _lib.StarNuggetError("xattn backward: gradient buffers do not share the input strides")
+        delta = torch.empty((B, h, L), dtype=torch.float32, device=dev)
+        dbias = part = None
+        if bias_f is not None:
+            part = torch.empty((B, h, Kn), dtype=torch.float32, device=dev)
+            dbias = torch.empty((B, bias_len), dtype=torch.float32, device=dev)
+        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
+        check(lib().star_xattn_bwd(ptr(qb), ptr(kb), ptr(vb), ptr(o), ptr(go), ptr(lse), ptr(bias_f), ptr(kl), s,
+                                   ptr(dq), ptr(dk), ptr(dv), ptr(delta), ptr(part), ptr(dbias), 0, stream_ptr()),
+              "star_xattn_bwd")
+        dt = ctx.in_dtype
+        if dt != torch.bfloat16:
+            dq, dk, dv = dq.to(dt), dk.to(dt), dv.to(dt)
+        if dbias is not None and ctx.bias_dtype != torch.float32:
+            dbias = dbias.to(ctx.bias_dtype)
+        return dq, dk, dv, dbias, None, None, None, None
+
+
+def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[float] = None,
+          need_probs: bool = False):
+    """q [B,h,L,hd]; k, v [B,h,Kn,hd]; bias [B,bias_len<=Kn] fp32 added to every query's logits; key_len [B]
+    masks keys >= key_len[b]; ilk_diag >= 0 enables the infinite-lookback mask (key j visible iff j <= i+diag).
+    Returns (O [B,h,L,hd] (memory order [B,L,h,hd]), P or None)."""
+    _need_cuda(q, k, v, bias, key_len)
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    return _XAttn.apply(q, k, v, bias, key_len, int(ilk_diag), float(scale), bool(need_probs))

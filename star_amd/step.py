@@ -1,0 +1,121 @@
+"""NuggetStep: one pass of the hot path over one batch -- what smoke() and bench.py run.
+
+  non-streaming (w2v_asr.py:528-585):  scorer -> top-k select (+type table) -> row gather ->
+      nl x score-biased cross-attention core -> loss -> backward to scorer params, X, S, Q.
+  simultaneous  (w2v_simul.py:407-465): scorer(X.detach()) -> quantity loss -> resize -> fire scan ->
+      score gather / type table / row gather -> nl x core (ILK optional) -> loss + 0.01*quantity.
+
+Out-of-scope neighbours of the path (wav2vec2 encoder, semantic encoder, decoder self-attention/MLP and
+the q_attn/c_attn GEMMs) are replaced by synthetic inputs: X are the encoder states, S the semantic states,
+Q_l the per-layer decoder queries, and K_l/V_l are a fixed diagonal linear map of the gathered memory.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .nugget import NuggetScorer
+
+
+@dataclass
+class StepInputs:
+    x: torch.Tensor                 # [B,T,d] bf16 encoder states (scorer input)
+    s: torch.Tensor                 # [B,T,d] bf16 semantic-encoder states (gather source)
+    lengths: Sequence[int]          # valid frames per utterance (host)
+    lengths_dev: torch.Tensor       # same, int32 on device
+    qs: List[torch.Tensor]          # nl x [B,h,L,hd] bf16 decoder queries
+    gs: List[torch.Tensor]          # nl x [B,h,L,hd] bf16 fixed cotangents
+    kv_scales: List[tuple]          # nl x (ak[d], av[d]) bf16 diagonal K/V maps
+    target_lengths: Optional[Sequence[int]] = None      # simul only (host)
+    target_lengths_dev: Optional[torch.Tensor] = None
+    cache: Optional[dict] = None    # per-rate device copies of host-derived tensors (kept out of the timed step)
+
+    def key_len_dev(self, rate):
+        """k_b per utterance as an int32 device tensor (computed once per rate, outside any graph capture)."""
+        if self.cache is None:
+            self.cache = {}
+        if rate not in self.cache:
+            kb = ops.nugget_counts_host(self.lengths, rate).astype(np.int32)
+            self.cache[rate] = (torch.from_numpy(kb).to(self.x.device), int(kb.max()))
+        return self.cache[rate]
+
+
+def make_inputs(lengths, T, d, h, L, nl, device, seed=1234, target_lengths=None, requires_grad=True) -> StepInputs:
+    """Seeded synthetic wav2vec2-shaped inputs: X ~ N(0,1) row-normalised, bf16."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    B = len(lengths)
+    hd = d // h
+
+    def states():
+        t = torch.randn(B, T, d, generator=g)
+        t = (t - t.mean(-1, keepdim=True)) / t.std(-1, keepdim=True)
+        return t.to(torch.bfloat16).to(device).requires_grad_(requires_grad)
+
+    x, s = states(), states()
+    qs = [torch.randn(B, h, L, hd, generator=g).to(torch.bfloat16).to(device).requires_grad_(requires_grad)
+          for _ in range(nl)]
+    gs = [(torch.randn(B, h, L, hd, generator=g) / (L * hd) ** 0.5).to(torch.bfloat16).to(device) for _ in range(nl)]
+    kv = [((1.0 + 0.25 * torch.randn(d, generator=g)).to(torch.bfloat16).to(device),
+           (1.0 + 0.25 * torch.randn(d, generator=g)).to(torch.bfloat16).to(device)) for _ in range(nl)]
+    ld = torch.tensor(list(lengths), dtype=torch.int32, device=device)
+    tl = None if target_lengths is None else torch.tensor(list(target_lengths), dtype=torch.int32, device=device)
+    return StepInputs(x, s, list(lengths), ld, qs, gs, kv, None if target_lengths is None else list(target_lengths), tl)
+
+
+def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag):
+    B, K, d = mem.shape
+    h = inp.qs[0].shape[1]
+    loss = None
+    for q, g, (ak, av) in zip(inp.qs, inp.gs, inp.kv_scales):
+        k = (mem * ak).view(B, K, h, d // h).permute(0, 2, 1, 3)
+        v = (mem * av).view(B, K, h, d // h).permute(0, 2, 1, 3)
+        o, _ = ops.xattn(q, k, v, bias=bias, key_len=key_len, ilk_diag=ilk_diag)
+        term = (o.float() * g.float()).sum()
+        loss = term if loss is None else loss + term
+    return loss
+
+
+def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward: bool = True):
+    """Non-streaming NuggetStep.  Host-known lengths size the outputs, so the step has no device->host sync
+    (and can be captured in a HIP graph).  Returns a dict of the step's observable results."""
+    B, T, d = inp.x.shape
+    key_len, K = inp.key_len_dev(rate)
+    scores = scorer(inp.x).squeeze(-1).float()
+    nmask, idx, sg, table, pos = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K)
+    # frames that can receive a score gradient: the B*K selected slots (pad slots get exact zeros)
+    rows = (idx + torch.arange(B, device=idx.device).unsqueeze(1) * T).to(torch.int32).reshape(-1)
+    scorer.set_active_rows(rows)
+    mem = ops.gather_rows(inp.s, idx)
+    loss = _attend(inp, mem, sg, key_len, -1)
+    if backward:
+        loss.backward()
+    return {"scores": scores, "nugget_mask": nmask, "indices": idx, "scores_gather": sg, "type_table": table,
+            "positions": pos, "mem": mem, "loss": loss}
+
+
+def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, backward: bool = True,
+                      cap: Optional[int] = None):
+    """Simultaneous NuggetStep (CIF-regularised scorer + fire scan, ILK optional).  The number of fires per
+    utterance is at most L_b + 1 after `resize`, so cap = max(L_b) + 2 sizes the outputs without a sync."""
+    B, T, d = inp.x.shape
+    if cap is None:
+        cap = int(max(inp.target_lengths)) + 2
+    scorer.set_active_rows(None)                       # every valid frame gets the quantity-loss gradient
+    scores = scorer(inp.x.detach()).squeeze(-1).float()                                  # w2v_simul.py:410-411
+    alphas, qloss = ops.cif_quantity(scores, inp.target_lengths_dev, lengths=inp.lengths_dev)  # :419-424
+    resized = ops.cif_resize(alphas, inp.target_lengths_dev)                            # :425
+    idx, nmask, counts, mx, _ = ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap)  # :426
+    nugget_scores = ops.gather_rows(scores, idx)                                         # :427
+    table, pos = ops.type_table(idx, nmask, T)                                           # :431
+    mem = ops.gather_rows(inp.s, idx)                                                    # :446-447
+    loss = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1)
+    total = loss + 0.01 * qloss                                                          # :461
+    if backward:
+        total.backward()
+    return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
+            "nugget_mask": nmask, "counts": counts, "max_count": mx, "scores_gather": nugget_scores,
+            "type_table": table, "positions": pos, "mem": mem, "loss": total}
