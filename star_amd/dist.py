@@ -1,0 +1,89 @@
+"""Multi-GPU: one process per GPU, utterances sharded across ranks, ONE flat gradient all-reduce per step.
+
+The reference uses Lightning's DDPStrategy over NCCL (train_w2v.py:195-196, train_simul.py:197-198): per-rank
+replicas, the batch split by the distributed sampler, bucketed gradient all-reduce during backward.  The hot
+path has no activation exchange (every utterance is independent through scorer, select, scan, gather and
+cross-attention), so here each rank runs the NuggetStep on its own utterances and the step ends with a single
+all-reduce (mean) of the flattened parameter gradients over RCCL/xGMI (backend "nccl" on ROCm); on CPU the
+same code runs over gloo (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment. Returns (rank, local_rank, world_size)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard(items: Sequence, rank: int, world: int) -> List:
+    """Utterances of a global batch owned by `rank`: a contiguous, near-equal slice (sizes differ by <= 1)."""
+    n = len(items)
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return list(items[lo:hi])
+
+
+class FlatGradAllReduce:
+    """All-reduce (mean) of the gradients of `params` as one flat buffer -> one collective per step.
+
+    A ring all-reduce over xGMI is per-link bound, so fewer, larger messages win; the scorer's gradients are
+    4.2 MB in fp32 at d = 1024, far below the point where bucketing would help."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=p0.device)
+
+    def __call__(self, world: int | None = None):
+        world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        o = 0
+        views = []
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[o:o + n].view_as(p)
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+            views.append(v)
+            o += n
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                p.grad = v.clone().to(p.dtype)
+            else:
+                p.grad.copy_(v)
+        return self.flat
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
