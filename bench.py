@@ -79,7 +79,7 @@ def cpu_baseline(args, seconds):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
+        if el >= seconds:
             break
     return {"value": B * T * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of B={B} x T={T} (d={d}, rate={args.rate}, {nl} layers, L={L}), fp32 torch-CPU oracle, "
