@@ -75,6 +75,16 @@ int star_gather_rows_fwd(const void* src, const int64_t* idx, void* dst, int B, 
 int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* dsrc, int B, int T, int K,
                          int d, int dtype, void* stream);
 
+/* Diagonal K/V fan-out.  NOT a reference operator: the NuggetStep harness derives the
+ * per-layer K_l / V_l from the gathered memory with a fixed diagonal linear map standing in for the c_attn
+ * GEMM (row a9, left to hipBLASLt); these two kernels keep that stand-in at one pass over the data.
+ *   fwd: out[j][r][:] = mem[r][:] * scales[j][:]      mem [R,d], scales [J,d], out [J,R,d], all bf16, J <= 16
+ *   bwd: dmem[r][:]   = sum_j grads[j][r][:] * scales[j][:]   (fp32 accumulate); grads_host is a HOST array
+ *        of J device pointers, each a dense [R,d] bf16 buffer. */
+int star_diag_fanout_fwd(const void* mem, const void* scales, int J, int64_t R, int d, void* out, void* stream);
+int star_diag_fanout_bwd(const void* const* grads_host, int J, const void* scales, int64_t R, int d, void* dmem,
+                         void* stream);
+
 /* ---------------------------------------------------------------- a5: CIF quantity loss
  * Replaces w2v_simul.py:419-424.  alphas = sigmoid(scores)*mask; diff_b = sum_t alphas/thr - L_b;
  * loss = mean_b diff_b^2.  attn_mask/lengths as in star_topk_select.  target_lengths [B] int32.

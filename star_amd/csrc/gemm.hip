@@ -49,7 +49,7 @@ struct GemmParams {
     __bf16* G;                // EPI_DH: [Mpad][N]
     __bf16* GT;               // EPI_DH: [N][Mpad]
     int64_t ldgt;
-    float* colpart;           // EPI_DH: [2][nbm][N]  (0: dw2, 1: db1)
+    float* colpart;           // EPI_DH: [2][nbm][N]  (0: dw2, 1: db1), then [nbm] partial sums of ds (db2)
     float* slab;              // EPI_SLAB: [splits][M][N]
     __bf16* out;              // EPI_ROWS: out[out_rows[m]][n]
     int64_t ldo;
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             c_dw2[tn] = 0.f;
             c_db1[tn] = 0.f;
         }
+        float ds_sum = 0.f;
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
             float dsv[4];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
                 dsv[j] = (m < p.a_rows_n) ? p.ds[p.a_rows[m]] : 0.f;
+                ds_sum += dsv[j];
             }
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
@@ -225,7 +227,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                 red[(c * 2 + wr) * 2 + 1] = c_db1[tn];
             }
         }
+        // db2 partial: sum of ds over this tile's 128 rows (lanes 0,16,32,48 hold 16 distinct rows each)
+        ds_sum += __shfl_xor(ds_sum, 16, 64);
+        ds_sum += __shfl_xor(ds_sum, 32, 64);
+        if (lane == 0 && wc == 0) red[512 + wr] = ds_sum;
         __syncthreads();
+        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red[512] + red[513];
         if (tid < BN) {
             const int64_t o = (int64_t)m_tile * p.N + n0 + tid;
             p.colpart[o] = red[(tid * 2 + 0) * 2 + 0] + red[(tid * 2 + 1) * 2 + 0];
@@ -333,18 +340,10 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
         dw2[i] = a;
         db1[i] = b;
     }
-    if (blockIdx.x == gridDim.x - 1) {
-        // last block: db2 (fixed-order tree over 256 threads)
-        __shared__ float red[256];
+    if (i == 0) {
         float s = 0.f;
-        for (int64_t r = threadIdx.x; r < R; r += 256) s += ds[rows[r]];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) db2[0] = red[0];
+        for (int t = 0; t < nbm; ++t) s += colpart[(int64_t)2 * nbm * d + t];
+        db2[0] = s;
     }
 }
 
@@ -425,7 +424,7 @@ extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
     const int64_t Rpad = round_up(R, BM);
     const int nbm = (int)(Rpad / BM);
     size_t g = align256((size_t)Rpad * d * 2);
-    return 3 * g + align256((size_t)2 * nbm * d * 4) + align256((size_t)bwd_splits(d) * d * d * 4);
+    return 3 * g + align256(((size_t)2 * nbm * d + nbm) * 4) + align256((size_t)bwd_splits(d) * d * d * 4);
 }
 
 extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1, const float* w2,
@@ -452,7 +451,7 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     __bf16* GT = (__bf16*)(ws + gbytes);
     __bf16* XT = (__bf16*)(ws + 2 * gbytes);
     float* colpart = (float*)(ws + 3 * gbytes);
-    float* slab = (float*)(ws + 3 * gbytes + align256((size_t)2 * nbm * d * 4));
+    float* slab = (float*)(ws + 3 * gbytes + align256(((size_t)2 * nbm * d + nbm) * 4));
 
     // 1. recompute H for the listed rows, emit G = dH and G^T, column partials for dw2 / db1
     GemmParams p = {};

@@ -26,6 +26,9 @@ namespace star {
 constexpr int XA_THREADS = 256;
 constexpr int KT = 64;          // keys per LDS tile (forward, dQ)
 constexpr float NEG_SENTINEL = -1.0e30f;
+#ifndef XA_ABLATE
+#define XA_ABLATE 0
+#endif
 
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -51,16 +54,42 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
     return r;
 }
 
-// copy rows [r0, r0+nrows) x HD of a strided bf16 matrix into an LDS tile (zero rows beyond `limit`)
-template <int HD>
-__device__ __forceinline__ void stage_tile(const __bf16* __restrict__ g, int64_t sr, int r0, int nrows, int limit,
-                                           uint8_t* tile, int pitch) {
-    constexpr int CPR = HD / 8;  // 16-B chunks per row
-    for (int c = threadIdx.x; c < nrows * CPR; c += XA_THREADS) {
-        const int row = c / CPR, ch = c % CPR;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r0 + row < limit) v = *(const u32x4*)(g + (int64_t)(r0 + row) * sr + ch * 8);
-        *(u32x4*)(tile + row * pitch + ch * 16) = v;
+// Register-staged tile copy, split in two halves so that the global loads of tile t+1 are in flight
+// while tile t is being consumed (issue early / write late):
+//   tile_load : rows [r0, r0+ROWS) x HD of a strided bf16 matrix -> registers (rows >= limit read as zero;
+//               addresses are clamped so every load is unconditional and the compiler batches them)
+//   tile_store: registers -> LDS tile with the given pitch
+template <int HD, int ROWS>
+struct TileRegs {
+    static constexpr int CPR = HD / 8;                       // 16-B chunks per row
+    static constexpr int TOTAL = ROWS * CPR;
+    static constexpr int N = (TOTAL + XA_THREADS - 1) / XA_THREADS;
+    u32x4 v[N];
+};
+
+template <int HD, int ROWS>
+__device__ __forceinline__ void tile_load(TileRegs<HD, ROWS>& t, const __bf16* __restrict__ g, int64_t sr, int r0,
+                                          int limit) {
+    using TR = TileRegs<HD, ROWS>;
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) {
+        const int c = threadIdx.x + i * XA_THREADS;
+        const int row = c / TR::CPR, ch = c % TR::CPR;
+        const int rr = min(r0 + row, limit - 1);
+        u32x4 v = *(const u32x4*)(g + (int64_t)rr * sr + ch * 8);
+        const bool ok = (r0 + row < limit);
+        t.v[i] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+
+template <int HD, int ROWS>
+__device__ __forceinline__ void tile_store(const TileRegs<HD, ROWS>& t, uint8_t* tile, int pitch) {
+    using TR = TileRegs<HD, ROWS>;
+#pragma unroll
+    for (int i = 0; i < TR::N; ++i) {
+        const int c = threadIdx.x + i * XA_THREADS;
+        const int row = c / TR::CPR, ch = c % TR::CPR;
+        if (TR::TOTAL % XA_THREADS == 0 || c < TR::TOTAL) *(u32x4*)(tile + row * pitch + ch * 16) = t.v[i];
     }
 }
 
@@ -103,15 +132,28 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
         for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
     float m_run = NEG_SENTINEL, l_run = 0.f;
 
+    auto load_bias = [&](int kt0) -> float {
+        const int key = kt0 + (tid & (KT - 1));
+        return (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
+    };
+    TileRegs<HD, KT> kreg, vreg;
+    float breg = 0.f;
+    if (kloop > 0) {
+        tile_load<HD, KT>(kreg, Kb, s.k_sr, 0, s.Kn);
+        tile_load<HD, KT>(vreg, Vb, s.v_sr, 0, s.Kn);
+        breg = load_bias(0);
+    }
     for (int kt0 = 0; kt0 < kloop; kt0 += KT) {
+        __syncthreads();                       // every wave is done reading the previous tile
+        tile_store<HD, KT>(kreg, k_lds, PK);
+        tile_store<HD, KT>(vreg, v_lds, PV);
+        if (tid < KT) b_lds[tid] = breg;
         __syncthreads();
-        stage_tile<HD>(Kb, s.k_sr, kt0, KT, s.Kn, k_lds, PK);
-        stage_tile<HD>(Vb, s.v_sr, kt0, KT, s.Kn, v_lds, PV);
-        if (tid < KT) {
-            const int key = kt0 + tid;
-            b_lds[tid] = (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
+        if (XA_ABLATE != 4 && kt0 + KT < kloop) {                // next tile's loads fly while this tile is consumed
+            tile_load<HD, KT>(kreg, Kb, s.k_sr, kt0 + KT, s.Kn);
+            tile_load<HD, KT>(vreg, Vb, s.v_sr, kt0 + KT, s.Kn);
+            breg = load_bias(kt0 + KT);
         }
-        __syncthreads();
 
         // S^T[key][q] = sum_n K[key][n] Q[q][n]
         f32x16 sacc[2];
@@ -122,7 +164,8 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 kf = lds_row8(k_lds + (sub * 32 + r) * PK + (ks * 2 + hf) * 16);
-                sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+                if (XA_ABLATE != 3) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+                else asm volatile("" ::"v"(kf));
             }
         }
         // logits, masks, online softmax (the query is on the lane: all row reductions are in-lane)
@@ -141,13 +184,13 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = (XA_ABLATE == 1) ? (m_run - m_new) : __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = __expf(sacc[sub][i] - m_new);
+                const float p = (XA_ABLATE == 1) ? (sacc[sub][i] - m_new) : __expf(sacc[sub][i] - m_new);
                 sacc[sub][i] = p;
                 psum += p;
             }
@@ -170,7 +213,8 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
                     const int col = nt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
                     const uint8_t* p0 = v_lds + krow * PV + col * 2;
                     bf16x8 vf = lds_tr8(p0, p0 + 8 * PV);
-                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[nt], 0, 0, 0);
+                    if (XA_ABLATE != 2) oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[nt], 0, 0, 0);
+                    else asm volatile("" ::"v"(vf), "v"(pf));
                 }
             }
     }
@@ -260,15 +304,28 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[nt][i] = 0.f;
 
+    auto load_bias = [&](int kt0) -> float {
+        const int key = kt0 + (tid & (KT - 1));
+        return (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
+    };
+    TileRegs<HD, KT> kreg, vreg;
+    float breg = 0.f;
+    if (kloop > 0) {
+        tile_load<HD, KT>(kreg, Kb, s.k_sr, 0, s.Kn);
+        tile_load<HD, KT>(vreg, Vb, s.v_sr, 0, s.Kn);
+        breg = load_bias(0);
+    }
     for (int kt0 = 0; kt0 < kloop; kt0 += KT) {
         __syncthreads();
-        stage_tile<HD>(Kb, s.k_sr, kt0, KT, s.Kn, k_lds, PK);
-        stage_tile<HD>(Vb, s.v_sr, kt0, KT, s.Kn, v_lds, PV);
-        if (tid < KT) {
-            const int key = kt0 + tid;
-            b_lds[tid] = (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
-        }
+        tile_store<HD, KT>(kreg, k_lds, PK);
+        tile_store<HD, KT>(vreg, v_lds, PV);
+        if (tid < KT) b_lds[tid] = breg;
         __syncthreads();
+        if (kt0 + KT < kloop) {
+            tile_load<HD, KT>(kreg, Kb, s.k_sr, kt0 + KT, s.Kn);
+            tile_load<HD, KT>(vreg, Vb, s.v_sr, kt0 + KT, s.Kn);
+            breg = load_bias(kt0 + KT);
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x16 sacc, pacc;
@@ -355,8 +412,13 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(
     const bool key_ok = key < kend;
     const float my_bias = (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
 
-    stage_tile<HD>(Kb, s.k_sr, kb0, KB, s.Kn, k_lds, PR);
-    stage_tile<HD>(Vb, s.v_sr, kb0, KB, s.Kn, v_lds, PR);
+    {
+        TileRegs<HD, KB> kreg, vreg;
+        tile_load<HD, KB>(kreg, Kb, s.k_sr, kb0, s.Kn);
+        tile_load<HD, KB>(vreg, Vb, s.v_sr, kb0, s.Kn);
+        tile_store<HD, KB>(kreg, k_lds, PR);
+        tile_store<HD, KB>(vreg, v_lds, PR);
+    }
 
     f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -370,16 +432,26 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(
     if (s.ilk_diag >= 0) q_begin = max(0, (kb0 - s.ilk_diag) / QS * QS);
     const bool wg_live = kb0 < kend;
 
+    TileRegs<HD, QS> qreg, greg;
+    float lreg = 0.f, dreg = 0.f;
+    auto load_slice = [&](int q0) {
+        tile_load<HD, QS>(qreg, Qb, s.q_sr, q0, s.L);
+        tile_load<HD, QS>(greg, dOb, s.o_sr, q0, s.L);
+        const int qq = min(q0 + (tid & (QS - 1)), s.L - 1);
+        lreg = lse[((int64_t)b * s.h + h) * s.L + qq];
+        dreg = delta[((int64_t)b * s.h + h) * s.L + qq];
+    };
+    if (wg_live && q_begin < s.L) load_slice(q_begin);
     for (int q0 = q_begin; wg_live && q0 < s.L; q0 += QS) {
         __syncthreads();
-        stage_tile<HD>(Qb, s.q_sr, q0, QS, s.L, q_lds, PT);
-        stage_tile<HD>(dOb, s.o_sr, q0, QS, s.L, g_lds, PT);
+        tile_store<HD, QS>(qreg, q_lds, PT);
+        tile_store<HD, QS>(greg, g_lds, PT);
         if (tid < QS) {
-            const int qq = min(q0 + tid, s.L - 1);
-            lse_lds[tid] = lse[((int64_t)b * s.h + h) * s.L + qq];
-            del_lds[tid] = delta[((int64_t)b * s.h + h) * s.L + qq];
+            lse_lds[tid] = lreg;
+            del_lds[tid] = dreg;
         }
         __syncthreads();
+        if (q0 + QS < s.L) load_slice(q0 + QS);
         // S[q][key] = Q K^T and dP[q][key] = dO V^T  (key on the lane)
         f32x16 sacc, pacc;
 #pragma unroll

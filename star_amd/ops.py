@@ -165,6 +165,44 @@ def gather_rows(src, idx):
     return _GatherRows.apply(src, idx.to(torch.int64))
 
 
+class _DiagFanout(torch.autograd.Function):
+    """Harness stand-in for the per-layer c_attn projection: K_l/V_l = mem * scale_j (one pass fwd, one bwd)."""
+
+    @staticmethod
+    def forward(ctx, mem, scales):
+        B, K, d = mem.shape
+        J = scales.shape[0]
+        m = mem.detach().contiguous()
+        sc = scales.detach().to(torch.bfloat16).contiguous()
+        out = torch.empty((J, B, K, d), dtype=torch.bfloat16, device=mem.device)
+        check(lib().star_diag_fanout_fwd(ptr(m), ptr(sc), J, B * K, d, ptr(out), stream_ptr()), "star_diag_fanout_fwd")
+        ctx.save_for_backward(sc)
+        ctx.shape = (J, B, K, d)
+        return tuple(out[j] for j in range(J))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (sc,) = ctx.saved_tensors
+        J, B, K, d = ctx.shape
+        gs = []
+        for g in grads:
+            if g is None:
+                g = torch.zeros((B, K, d), dtype=torch.bfloat16, device=sc.device)
+            gs.append(g.to(torch.bfloat16).contiguous())
+        arr = (_lib.C.c_void_p * J)(*[g.data_ptr() for g in gs])
+        dmem = torch.empty((B, K, d), dtype=torch.bfloat16, device=sc.device)
+        check(lib().star_diag_fanout_bwd(arr, J, ptr(sc), B * K, d, ptr(dmem), stream_ptr()), "star_diag_fanout_bwd")
+        return dmem, None
+
+
+def diag_fanout(mem, scales):
+    """mem [B,K,d] bf16, scales [J,d] -> J tensors [B,K,d] (views of one buffer)."""
+    _need_cuda(mem, scales)
+    if mem.dtype != torch.bfloat16:
+        raise TypeError("diag_fanout: bf16 only")
+    return _DiagFanout.apply(mem, scales)
+
+
 # ----------------------------------------------------------------------------- a5
 class _CifQuantity(torch.autograd.Function):
     """alphas = sigmoid(scores)*mask; loss = mean((sum alphas/thr - L)^2)  (w2v_simul.py:419-424)."""
@@ -386,8 +424,11 @@ class _XAttn(torch.autograd.Function):
         Kn = kb.shape[2]
         dev = qb.device
         # dO must share o's strides
-        go = torch.empty_like(o)
-        go.copy_(g)
+        if g.dtype == torch.bfloat16 and g.stride() == o.stride():
+            go = g
+        else:
+            go = torch.empty_like(o)
+            go.copy_(g)
         dq = torch.empty_like(qb)
         dk = torch.empty_like(kb)
         dv = torch.empty_like(vb)

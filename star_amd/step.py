@@ -30,6 +30,7 @@ class StepInputs:
     qs: List[torch.Tensor]          # nl x [B,h,L,hd] bf16 decoder queries
     gs: List[torch.Tensor]          # nl x [B,h,L,hd] bf16 fixed cotangents
     kv_scales: List[tuple]          # nl x (ak[d], av[d]) bf16 diagonal K/V maps
+    kv_scales_flat: Optional[torch.Tensor] = None       # [2*nl, d] bf16: ak_0, av_0, ak_1, ...
     target_lengths: Optional[Sequence[int]] = None      # simul only (host)
     target_lengths_dev: Optional[torch.Tensor] = None
     cache: Optional[dict] = None    # per-rate device copies of host-derived tensors (kept out of the timed step)
@@ -58,28 +59,40 @@ def make_inputs(lengths, T, d, h, L, nl, device, seed=1234, target_lengths=None,
     x, s = states(), states()
     qs = [torch.randn(B, h, L, hd, generator=g).to(torch.bfloat16).to(device).requires_grad_(requires_grad)
           for _ in range(nl)]
-    gs = [(torch.randn(B, h, L, hd, generator=g) / (L * hd) ** 0.5).to(torch.bfloat16).to(device) for _ in range(nl)]
+    # cotangents live in [B,L,h,hd] memory order (the order the attention kernel writes O in)
+    gs = [(torch.randn(B, h, L, hd, generator=g) / (L * hd) ** 0.5).to(torch.bfloat16).permute(0, 2, 1, 3)
+          .contiguous().to(device).permute(0, 2, 1, 3) for _ in range(nl)]
     kv = [((1.0 + 0.25 * torch.randn(d, generator=g)).to(torch.bfloat16).to(device),
            (1.0 + 0.25 * torch.randn(d, generator=g)).to(torch.bfloat16).to(device)) for _ in range(nl)]
     ld = torch.tensor(list(lengths), dtype=torch.int32, device=device)
     tl = None if target_lengths is None else torch.tensor(list(target_lengths), dtype=torch.int32, device=device)
-    return StepInputs(x, s, list(lengths), ld, qs, gs, kv, None if target_lengths is None else list(target_lengths), tl)
+    flat = torch.stack([t for pair in kv for t in pair]).contiguous()
+    return StepInputs(x, s, list(lengths), ld, qs, gs, kv, flat,
+                      None if target_lengths is None else list(target_lengths), tl)
 
 
-def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag):
+def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag, with_loss: bool):
+    """nl x score-biased cross-attention on K_l/V_l = diag maps of the gathered memory.  Returns (outputs, loss):
+    the scalar loss sum_l <O_l, G_l> is only formed when asked for (tests); its gradient is exactly the cotangent
+    G_l, which the step feeds to backward directly."""
     B, K, d = mem.shape
     h = inp.qs[0].shape[1]
-    loss = None
-    for q, g, (ak, av) in zip(inp.qs, inp.gs, inp.kv_scales):
-        k = (mem * ak).view(B, K, h, d // h).permute(0, 2, 1, 3)
-        v = (mem * av).view(B, K, h, d // h).permute(0, 2, 1, 3)
+    kvs = ops.diag_fanout(mem, inp.kv_scales_flat)
+    outs = []
+    for l, q in enumerate(inp.qs):
+        k = kvs[2 * l].view(B, K, h, d // h).permute(0, 2, 1, 3)
+        v = kvs[2 * l + 1].view(B, K, h, d // h).permute(0, 2, 1, 3)
         o, _ = ops.xattn(q, k, v, bias=bias, key_len=key_len, ilk_diag=ilk_diag)
-        term = (o.float() * g.float()).sum()
-        loss = term if loss is None else loss + term
-    return loss
+        outs.append(o)
+    loss = None
+    if with_loss:
+        with torch.no_grad():
+            loss = sum((o.float() * g.float()).sum() for o, g in zip(outs, inp.gs))
+    return outs, loss
 
 
-def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward: bool = True):
+def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward: bool = True,
+                    with_loss: bool = False):
     """Non-streaming NuggetStep.  Host-known lengths size the outputs, so the step has no device->host sync
     (and can be captured in a HIP graph).  Returns a dict of the step's observable results."""
     B, T, d = inp.x.shape
@@ -90,15 +103,15 @@ def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward
     rows = (idx + torch.arange(B, device=idx.device).unsqueeze(1) * T).to(torch.int32).reshape(-1)
     scorer.set_active_rows(rows)
     mem = ops.gather_rows(inp.s, idx)
-    loss = _attend(inp, mem, sg, key_len, -1)
+    outs, loss = _attend(inp, mem, sg, key_len, -1, with_loss)
     if backward:
-        loss.backward()
+        torch.autograd.backward(outs, inp.gs)
     return {"scores": scores, "nugget_mask": nmask, "indices": idx, "scores_gather": sg, "type_table": table,
             "positions": pos, "mem": mem, "loss": loss}
 
 
 def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, backward: bool = True,
-                      cap: Optional[int] = None):
+                      cap: Optional[int] = None, with_loss: bool = False):
     """Simultaneous NuggetStep (CIF-regularised scorer + fire scan, ILK optional).  The number of fires per
     utterance is at most L_b + 1 after `resize`, so cap = max(L_b) + 2 sizes the outputs without a sync."""
     B, T, d = inp.x.shape
@@ -112,10 +125,10 @@ def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, back
     nugget_scores = ops.gather_rows(scores, idx)                                         # :427
     table, pos = ops.type_table(idx, nmask, T)                                           # :431
     mem = ops.gather_rows(inp.s, idx)                                                    # :446-447
-    loss = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1)
-    total = loss + 0.01 * qloss                                                          # :461
+    outs, loss = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1, with_loss)
+    total = None if loss is None else loss + 0.01 * qloss.detach()                       # :461
     if backward:
-        total.backward()
+        torch.autograd.backward(outs + [qloss], inp.gs + [torch.full_like(qloss, 0.01)])
     return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
             "nugget_mask": nmask, "counts": counts, "max_count": mx, "scores_gather": nugget_scores,
             "type_table": table, "positions": pos, "mem": mem, "loss": total}

@@ -424,7 +424,7 @@ def test_nugget_step_asr_vs_oracle(ops):
     lengths, T, d, h, L, nl, rate = [250, 230, 200, 170], 250, 768, 8, 24, 2, 4
     scorer = NuggetScorer(d).to(DEV)
     inp = make_inputs(lengths, T, d, h, L, nl, DEV)
-    out = nugget_step_asr(scorer, inp, rate)
+    out = nugget_step_asr(scorer, inp, rate, with_loss=True)
     # index parity on the scores produced by the SAME scorer implementation
     scores = out["scores"].detach().cpu().numpy()
     mask = lmask(lengths, T)
@@ -467,7 +467,7 @@ def test_nugget_step_simul_runs_and_matches_oracle_pieces(ops):
     inp = make_inputs(lengths, T, d, h, L, nl, DEV, target_lengths=tl)
     for ilk in (False, True):
         scorer.zero_grad()
-        out = nugget_step_simul(scorer, inp, use_ilk=ilk)
+        out = nugget_step_simul(scorer, inp, use_ilk=ilk, with_loss=True)
         mask = lmask(lengths, T)
         # fire positions: bit-exact against the oracle scan run on the kernel's own resized alphas
         o_mask, o_idx, _ = orc.fire_scan(out["resized"].cpu().numpy(), mask, with_block_mask=False)
