@@ -8,6 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["error.cpp", "select.hip", "gather.hip", "cif.hip", "gemm.hip", "xattn.hip"]
 LIB = os.path.join(HERE, "libstar_nugget.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# per-file extras (STAR_XATTN_FLAGS etc. override for experiments)
+EXTRA = {"xattn.hip": os.environ.get("STAR_XATTN_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form=1").split(),
+         "gemm.hip": os.environ.get("STAR_GEMM_FLAGS", "").split()}
 
 
 def _newer(a, b):
@@ -26,7 +29,7 @@ def build(force=False, verbose=True):
         op = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(d, op) for d in deps):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
             jobs.append(cmd)
 
     def run(cmd):

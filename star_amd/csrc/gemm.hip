@@ -322,28 +322,38 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
                                                                 int64_t dd, float* __restrict__ dw1,
                                                                 const float* __restrict__ colpart, int nbm, int d,
                                                                 float* __restrict__ dw2, float* __restrict__ db1,
-                                                                const float* __restrict__ ds,
-                                                                const int32_t* __restrict__ rows, int64_t R,
-                                                                float* __restrict__ db2) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < dd) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * dd + i];
-        dw1[i] = s;
-    }
-    if (i < d) {
-        float a = 0.f, b = 0.f;
-        for (int t = 0; t < nbm; ++t) {
-            a += colpart[(int64_t)t * d + i];
-            b += colpart[(int64_t)(nbm + t) * d + i];
+                                                                float* __restrict__ db2, int nblk_dw1) {
+    if ((int)blockIdx.x < nblk_dw1) {
+        // dw1: sum of the split-K slabs, 4 floats per thread
+        const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i < dd) {
+            f32x4 s = *(const f32x4*)(slab + i);
+            for (int k = 1; k < splits; ++k) {
+                const f32x4 v = *(const f32x4*)(slab + (int64_t)k * dd + i);
+                s += v;
+            }
+            *(f32x4*)(dw1 + i) = s;
         }
-        dw2[i] = a;
-        db1[i] = b;
+        return;
     }
-    if (i == 0) {
-        float s = 0.f;
-        for (int t = 0; t < nbm; ++t) s += colpart[(int64_t)2 * nbm * d + t];
-        db2[0] = s;
+    // column partials: block = 64 columns of [dw2 | db1]; thread (tx, ty): column tx, row-tiles t = ty mod 4
+    __shared__ float red[4][64];
+    const int cb = blockIdx.x - nblk_dw1;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = cb * 64 + tx;                  // 0 .. 2d-1
+    const int which = col / d, c = col % d;
+    float a = 0.f;
+    for (int t = ty; t < nbm; t += 4) a += colpart[((int64_t)which * nbm + t) * d + c];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0) {
+        const float sum = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        (which ? db1 : dw2)[c] = sum;
+    }
+    if (cb == 0 && threadIdx.x == 0) {
+        float s2 = 0.f;
+        for (int t = 0; t < nbm; ++t) s2 += colpart[(int64_t)2 * nbm * d + t];
+        db2[0] = s2;
     }
 }
 
@@ -490,8 +500,9 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     launch_gemm(EPI_SLAB, q, st);
     // 4. reductions
     const int64_t dd = (int64_t)d * d;
-    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(cdiv(dd, 256)), dim3(256), 0, st, (const float*)slab, splits, dd,
-                       dw1, (const float*)colpart, nbm, d, dw2, db1, dscores, rows, R, db2);
+    const int nblk_dw1 = cdiv(dd, 1024);
+    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(nblk_dw1 + 2 * d / 64), dim3(256), 0, st, (const float*)slab,
+                       splits, dd, dw1, (const float*)colpart, nbm, d, dw2, db1, db2, nblk_dw1);
     // 5. dX rows = G . W1
     if (dx) {
         GemmParams r = {};

@@ -20,15 +20,13 @@
 // Masked logits are -inf (P and dS exactly 0), the running max starts at a finite sentinel.
 // Algorithmic FLOP per (b, layer): forward 4*L*k_b*d, backward 8*L*k_b*d (+ 4*L*k_b*d recompute).
 #include "common.h"
+#include <stdlib.h>
 
 namespace star {
 
 constexpr int XA_THREADS = 256;
 constexpr int KT = 64;          // keys per LDS tile (forward, dQ)
 constexpr float NEG_SENTINEL = -1.0e30f;
-#ifndef XA_ABLATE
-#define XA_ABLATE 0
-#endif
 
 __device__ __forceinline__ int crow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -59,21 +57,22 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
 //   tile_load : rows [r0, r0+ROWS) x HD of a strided bf16 matrix -> registers (rows >= limit read as zero;
 //               addresses are clamped so every load is unconditional and the compiler batches them)
 //   tile_store: registers -> LDS tile with the given pitch
-template <int HD, int ROWS>
+// NTH = threads of the workgroup that take part.
+template <int HD, int ROWS, int NTH = XA_THREADS>
 struct TileRegs {
     static constexpr int CPR = HD / 8;                       // 16-B chunks per row
     static constexpr int TOTAL = ROWS * CPR;
-    static constexpr int N = (TOTAL + XA_THREADS - 1) / XA_THREADS;
+    static constexpr int N = (TOTAL + NTH - 1) / NTH;
     u32x4 v[N];
 };
 
-template <int HD, int ROWS>
-__device__ __forceinline__ void tile_load(TileRegs<HD, ROWS>& t, const __bf16* __restrict__ g, int64_t sr, int r0,
+template <int HD, int ROWS, int NTH>
+__device__ __forceinline__ void tile_load(TileRegs<HD, ROWS, NTH>& t, const __bf16* __restrict__ g, int64_t sr, int r0,
                                           int limit) {
-    using TR = TileRegs<HD, ROWS>;
+    using TR = TileRegs<HD, ROWS, NTH>;
 #pragma unroll
     for (int i = 0; i < TR::N; ++i) {
-        const int c = threadIdx.x + i * XA_THREADS;
+        const int c = threadIdx.x + i * NTH;
         const int row = c / TR::CPR, ch = c % TR::CPR;
         const int rr = min(r0 + row, limit - 1);
         u32x4 v = *(const u32x4*)(g + (int64_t)rr * sr + ch * 8);
@@ -82,35 +81,58 @@ __device__ __forceinline__ void tile_load(TileRegs<HD, ROWS>& t, const __bf16* _
     }
 }
 
-template <int HD, int ROWS>
-__device__ __forceinline__ void tile_store(const TileRegs<HD, ROWS>& t, uint8_t* tile, int pitch) {
-    using TR = TileRegs<HD, ROWS>;
+template <int HD, int ROWS, int NTH>
+__device__ __forceinline__ void tile_store(const TileRegs<HD, ROWS, NTH>& t, uint8_t* tile, int pitch) {
+    using TR = TileRegs<HD, ROWS, NTH>;
 #pragma unroll
     for (int i = 0; i < TR::N; ++i) {
-        const int c = threadIdx.x + i * XA_THREADS;
+        const int c = threadIdx.x + i * NTH;
         const int row = c / TR::CPR, ch = c % TR::CPR;
-        if (TR::TOTAL % XA_THREADS == 0 || c < TR::TOTAL) *(u32x4*)(tile + row * pitch + ch * 16) = t.v[i];
+        if (TR::TOTAL % NTH == 0 || c < TR::TOTAL) *(u32x4*)(tile + row * pitch + ch * 16) = t.v[i];
     }
 }
 
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 8.0f;   // log2 units: the running max is only raised when a tile exceeds it by 2^8
+
 // ============================================================================================ forward
-template <int HD>
-__global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ K,
-                                                               const __bf16* __restrict__ V, const float* __restrict__ bias,
-                                                               const int32_t* __restrict__ key_len, star_xattn_shape s,
-                                                               __bf16* __restrict__ O, float* __restrict__ lse) {
+// One workgroup = 128 queries of one (batch, head): NG groups of 4 waves, 32 queries per wave.  With NG = 2 the
+// two groups walk the SAME queries over alternating 64-key tiles (in-workgroup split-K), so every SIMD holds two
+// waves whose MFMA / softmax / LDS phases interleave; the partial (m, l, O) states are merged through LDS at the end.
+// All softmax arithmetic is in the log2 domain (logit2 = acc * scale*log2e + bias*log2e, p = exp2(logit2 - m2)).
+template <int HD, int NG>
+struct FwdLds {
+    static constexpr int PK = Pitch<HD>::ROW, PV = Pitch<HD>::TR;
+    static constexpr int K_BYTES = NG * KT * PK, V_BYTES = NG * KT * PV, B_BYTES = NG * KT * 4;
+    static constexpr int TILE_BYTES = K_BYTES + V_BYTES + B_BYTES;
+    static constexpr int MERGE_BYTES = (NG > 1) ? ((HD / 32) * 16 + 2) * 256 * 4 : 0;
+    static constexpr int BYTES = TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES;
+};
+
+template <int HD, int NG>
+__global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
+    const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
+    const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ O,
+    float* __restrict__ lse) {
+    constexpr int NTH = NG * 256, QB = 128, KSTEP = NG * KT;
     constexpr int PK = Pitch<HD>::ROW, PV = Pitch<HD>::TR;
     constexpr int KS = HD / 16, NT = HD / 32;
-    __shared__ __attribute__((aligned(16))) uint8_t k_lds[KT * PK];
-    __shared__ __attribute__((aligned(16))) uint8_t v_lds[KT * PV];
-    __shared__ float b_lds[KT];
+    extern __shared__ __attribute__((aligned(16))) uint8_t fwd_smem[];
+    uint8_t* k_all = fwd_smem;
+    uint8_t* v_all = k_all + FwdLds<HD, NG>::K_BYTES;
+    float* b_all = (float*)(v_all + FwdLds<HD, NG>::V_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = wid >> 2, qw = wid & 3;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qblk0 = blockIdx.x * 128;
-    const int q = qblk0 + wid * 32 + r;            // this lane's query row
+    const int qblk0 = blockIdx.x * QB;
+    const int q = qblk0 + qw * 32 + r;            // this lane's query row
     const int qc = min(q, s.L - 1);
+    const uint8_t* k_lds = k_all + grp * KT * PK;
+    const uint8_t* v_lds = v_all + grp * KT * PV;
+    const float* b_lds = b_all + grp * KT;
 
     const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
     const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
@@ -123,7 +145,8 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     int kloop = kend;                                // keys any query of this workgroup can see
-    if (s.ilk_diag >= 0) kloop = min(kloop, min(qblk0 + 128, s.L) + s.ilk_diag);
+    if (s.ilk_diag >= 0) kloop = min(kloop, min(qblk0 + QB, s.L) + s.ilk_diag);
+    const float scale2 = s.scale * LOG2E;
 
     f32x16 oacc[NT];
 #pragma unroll
@@ -133,27 +156,31 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
     float m_run = NEG_SENTINEL, l_run = 0.f;
 
     auto load_bias = [&](int kt0) -> float {
-        const int key = kt0 + (tid & (KT - 1));
-        return (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
+        const int key = kt0 + (tid & (KSTEP - 1));
+        float v = 0.f;
+        if (bias && s.bias_len > 0) v = bias[(int64_t)b * s.bias_len + min(key, s.bias_len - 1)];
+        return (key < s.bias_len) ? v * LOG2E : 0.f;
     };
-    TileRegs<HD, KT> kreg, vreg;
+    TileRegs<HD, KSTEP, NTH> kreg, vreg;
     float breg = 0.f;
     if (kloop > 0) {
-        tile_load<HD, KT>(kreg, Kb, s.k_sr, 0, s.Kn);
-        tile_load<HD, KT>(vreg, Vb, s.v_sr, 0, s.Kn);
+        tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, 0, s.Kn);
+        tile_load<HD, KSTEP, NTH>(vreg, Vb, s.v_sr, 0, s.Kn);
         breg = load_bias(0);
     }
-    for (int kt0 = 0; kt0 < kloop; kt0 += KT) {
-        __syncthreads();                       // every wave is done reading the previous tile
-        tile_store<HD, KT>(kreg, k_lds, PK);
-        tile_store<HD, KT>(vreg, v_lds, PV);
-        if (tid < KT) b_lds[tid] = breg;
+    for (int kt0 = 0; kt0 < kloop; kt0 += KSTEP) {
+        __syncthreads();                       // every wave is done reading the previous tiles
+        tile_store<HD, KSTEP, NTH>(kreg, k_all, PK);
+        tile_store<HD, KSTEP, NTH>(vreg, v_all, PV);
+        if (tid < KSTEP) b_all[tid] = breg;
         __syncthreads();
-        if (XA_ABLATE != 4 && kt0 + KT < kloop) {                // next tile's loads fly while this tile is consumed
-            tile_load<HD, KT>(kreg, Kb, s.k_sr, kt0 + KT, s.Kn);
-            tile_load<HD, KT>(vreg, Vb, s.v_sr, kt0 + KT, s.Kn);
-            breg = load_bias(kt0 + KT);
+        if (kt0 + KSTEP < kloop) {             // next tiles' loads fly while these are consumed
+            tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, kt0 + KSTEP, s.Kn);
+            tile_load<HD, KSTEP, NTH>(vreg, Vb, s.v_sr, kt0 + KSTEP, s.Kn);
+            breg = load_bias(kt0 + KSTEP);
         }
+        const int kbase = kt0 + grp * KT;      // first key of this group's tile
+        if (kbase >= kloop) continue;          // (wave-uniform) nothing visible in this tile
 
         // S^T[key][q] = sum_n K[key][n] Q[q][n]
         f32x16 sacc[2];
@@ -164,42 +191,57 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 kf = lds_row8(k_lds + (sub * 32 + r) * PK + (ks * 2 + hf) * 16);
-                if (XA_ABLATE != 3) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
-                else asm volatile("" ::"v"(kf));
+                sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
             }
         }
-        // logits, masks, online softmax (the query is on the lane: all row reductions are in-lane)
+        // logits (log2 domain) + bias; the 4 consecutive keys of a register group share one 16-B bias read
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *(const f32x4*)(b_lds + sub * 32 + 8 * g + 4 * hf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc[sub][g * 4 + j] = sacc[sub][g * 4 + j] * scale2 + bb[j];
+            }
+        // masks only on tiles that need them (wave-uniform test): partial last tile, ILK diagonal
+        const bool need_mask = (kbase + KT > kend) || (s.ilk_diag >= 0 && kbase + KT - 1 > qblk0 + qw * 32 + s.ilk_diag);
+        if (need_mask) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kbase + sub * 32 + crow(i, hf);
+                    const bool vis = (key < kend) && (s.ilk_diag < 0 || key <= q + s.ilk_diag);
+                    sacc[sub][i] = vis ? sacc[sub][i] : -INFINITY;
+                }
+        }
         float mx = NEG_SENTINEL;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kl = sub * 32 + crow(i, hf);
-                const int key = kt0 + kl;
-                float v = sacc[sub][i] * s.scale + b_lds[kl];
-                const bool vis = (key < kend) && (s.ilk_diag < 0 || key <= q + s.ilk_diag);
-                v = vis ? v : -INFINITY;
-                sacc[sub][i] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[sub][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = (XA_ABLATE == 1) ? (m_run - m_new) : __expf(m_run - m_new);
+        // lazy rescale: raise the running max only when some row of the wave exceeds it by 2^RESCALE_THR
+        if (!__all(mx <= m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[nt][i] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = (XA_ABLATE == 1) ? (sacc[sub][i] - m_new) : __expf(sacc[sub][i] - m_new);
+                const float p = __builtin_amdgcn_exp2f(sacc[sub][i] - m_run);
                 sacc[sub][i] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[nt][i] *= alpha;
+        l_run += psum;
 
         // O^T[n][q] += sum_key V[key][n] P[q][key]   (A = V^T via transposed LDS reads, B = P^T accumulator)
 #pragma unroll
@@ -213,10 +255,35 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
                     const int col = nt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
                     const uint8_t* p0 = v_lds + krow * PV + col * 2;
                     bf16x8 vf = lds_tr8(p0, p0 + 8 * PV);
-                    if (XA_ABLATE != 2) oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[nt], 0, 0, 0);
-                    else asm volatile("" ::"v"(vf), "v"(pf));
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[nt], 0, 0, 0);
                 }
             }
+    }
+
+    if constexpr (NG > 1) {
+        // merge the two key groups' partial softmax states (same lane <-> same query / register layout)
+        float* mrg = (float*)fwd_smem;
+        const int slot = qw * 64 + lane;
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = oacc[nt][i];
+            mrg[(NT * 16) * 256 + slot] = m_run;
+            mrg[(NT * 16 + 1) * 256 + slot] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = mrg[(NT * 16) * 256 + slot], l1 = mrg[(NT * 16 + 1) * 256 + slot];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = exp2f(m_run - m), a1 = exp2f(m1 - m);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[nt][i] = oacc[nt][i] * a0 + mrg[(nt * 16 + i) * 256 + slot] * a1;
+        l_run = l_run * a0 + l1 * a1;
+        m_run = m;
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -232,71 +299,74 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_fwd_kernel(const __bf16* __r
                 for (int j = 0; j < 4; ++j) o4[j] = (__bf16)(oacc[nt][g * 4 + j] * inv);
                 *(bf16x4*)(orow + nt * 32 + 8 * g + 4 * hf) = o4;
             }
-        if (hf == 0) lse[((int64_t)b * s.h + h) * s.L + q] = l_tot > 0.f ? m_run + __logf(l_tot) : 0.f;
+        // natural-log LSE of the masked, biased logits
+        if (hf == 0) lse[((int64_t)b * s.h + h) * s.L + q] = l_tot > 0.f ? (m_run + __log2f(l_tot)) * LN2 : 0.f;
     }
 }
 
-// ============================================================================================ delta
-// delta[b,h,q] = sum_n dO[q][n] * O[q][n]
-template <int HD>
-__global__ __launch_bounds__(XA_THREADS) void xattn_delta_kernel(const __bf16* __restrict__ O, const __bf16* __restrict__ dO,
-                                                                 star_xattn_shape s, float* __restrict__ delta) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wid;           // flat (b,h,q)
-    const int64_t total = (int64_t)s.B * s.h * s.L;
-    if (row >= total) return;
-    const int q = (int)(row % s.L);
-    const int h = (int)((row / s.L) % s.h);
-    const int b = (int)(row / ((int64_t)s.L * s.h));
-    const int64_t off = (int64_t)b * s.o_sb + (int64_t)h * s.o_sh + (int64_t)q * s.o_sr;
-    float acc = 0.f;
-    for (int c = lane; c < HD / 2; c += 64) {
-        bf16x2 a = *(const bf16x2*)(O + off + c * 2);
-        bf16x2 g = *(const bf16x2*)(dO + off + c * 2);
-        acc += (float)a[0] * (float)g[0] + (float)a[1] * (float)g[1];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) delta[row] = acc;
-}
+// ============================================================================================ dQ (+ delta)
+// Same walk as the forward (query on the lane, NG key groups merged through LDS).  delta = rowsum(dO*O) is
+// computed here from the fragments the kernel holds anyway and written out for the dK/dV kernel.
+template <int HD, int NG>
+struct DqLds {
+    static constexpr int PK = Pitch<HD>::TR, PV = Pitch<HD>::ROW;
+    static constexpr int K_BYTES = NG * KT * PK, V_BYTES = NG * KT * PV, B_BYTES = NG * KT * 4;
+    static constexpr int TILE_BYTES = K_BYTES + V_BYTES + B_BYTES;
+    static constexpr int MERGE_BYTES = (NG > 1) ? (HD / 32) * 16 * 256 * 4 : 0;
+    static constexpr int BYTES = TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES;
+};
 
-// ============================================================================================ dQ
-template <int HD>
-__global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
+template <int HD, int NG>
+__global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
-    const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
-    const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dQ) {
+    const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
+    float* __restrict__ delta, const float* __restrict__ bias, const int32_t* __restrict__ key_len,
+    star_xattn_shape s, __bf16* __restrict__ dQ) {
+    constexpr int NTH = NG * 256, QB = 128, KSTEP = NG * KT;
     constexpr int PK = Pitch<HD>::TR;   // K: row reads (S^T) and transposed reads (dQ^T)
     constexpr int PV = Pitch<HD>::ROW;  // V: row reads only
     constexpr int KS = HD / 16, NT = HD / 32;
-    __shared__ __attribute__((aligned(16))) uint8_t k_lds[KT * PK];
-    __shared__ __attribute__((aligned(16))) uint8_t v_lds[KT * PV];
-    __shared__ float b_lds[KT];
+    extern __shared__ __attribute__((aligned(16))) uint8_t dq_smem[];
+    uint8_t* k_all = dq_smem;
+    uint8_t* v_all = k_all + DqLds<HD, NG>::K_BYTES;
+    float* b_all = (float*)(v_all + DqLds<HD, NG>::V_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = wid >> 2, qw = wid & 3;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qblk0 = blockIdx.x * 128;
-    const int q = qblk0 + wid * 32 + r;
+    const int qblk0 = blockIdx.x * QB;
+    const int q = qblk0 + qw * 32 + r;
     const int qc = min(q, s.L - 1);
+    const uint8_t* k_lds = k_all + grp * KT * PK;
+    const uint8_t* v_lds = v_all + grp * KT * PV;
+    const float* b_lds = b_all + grp * KT;
 
     const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
     const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
     const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+    const __bf16* Ob = O + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
     const __bf16* dOb = dO + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
 
     bf16x8 qf[KS], gf[KS];
+    float my_delta = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * s.q_sr + ks * 16 + hf * 8);
         gf[ks] = *(const bf16x8*)(dOb + (int64_t)qc * s.o_sr + ks * 16 + hf * 8);
+        const bf16x8 of = *(const bf16x8*)(Ob + (int64_t)qc * s.o_sr + ks * 16 + hf * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) my_delta += (float)gf[ks][j] * (float)of[j];
     }
-    const float my_lse = lse[((int64_t)b * s.h + h) * s.L + qc];
-    const float my_delta = delta[((int64_t)b * s.h + h) * s.L + qc];
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (grp == 0 && hf == 0 && q < s.L) delta[((int64_t)b * s.h + h) * s.L + q] = my_delta;
+    const float my_lse2 = lse[((int64_t)b * s.h + h) * s.L + qc] * LOG2E;
 
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     int kloop = kend;
-    if (s.ilk_diag >= 0) kloop = min(kloop, min(qblk0 + 128, s.L) + s.ilk_diag);
+    if (s.ilk_diag >= 0) kloop = min(kloop, min(qblk0 + QB, s.L) + s.ilk_diag);
+    const float scale2 = s.scale * LOG2E;
 
     f32x16 dq[NT];
 #pragma unroll
@@ -305,27 +375,32 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
         for (int i = 0; i < 16; ++i) dq[nt][i] = 0.f;
 
     auto load_bias = [&](int kt0) -> float {
-        const int key = kt0 + (tid & (KT - 1));
-        return (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
+        const int key = kt0 + (tid & (KSTEP - 1));
+        float v = 0.f;
+        if (bias && s.bias_len > 0) v = bias[(int64_t)b * s.bias_len + min(key, s.bias_len - 1)];
+        return (key < s.bias_len) ? v * LOG2E : 0.f;
     };
-    TileRegs<HD, KT> kreg, vreg;
+    TileRegs<HD, KSTEP, NTH> kreg, vreg;
     float breg = 0.f;
     if (kloop > 0) {
-        tile_load<HD, KT>(kreg, Kb, s.k_sr, 0, s.Kn);
-        tile_load<HD, KT>(vreg, Vb, s.v_sr, 0, s.Kn);
+        tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, 0, s.Kn);
+        tile_load<HD, KSTEP, NTH>(vreg, Vb, s.v_sr, 0, s.Kn);
         breg = load_bias(0);
     }
-    for (int kt0 = 0; kt0 < kloop; kt0 += KT) {
+    for (int kt0 = 0; kt0 < kloop; kt0 += KSTEP) {
         __syncthreads();
-        tile_store<HD, KT>(kreg, k_lds, PK);
-        tile_store<HD, KT>(vreg, v_lds, PV);
-        if (tid < KT) b_lds[tid] = breg;
+        tile_store<HD, KSTEP, NTH>(kreg, k_all, PK);
+        tile_store<HD, KSTEP, NTH>(vreg, v_all, PV);
+        if (tid < KSTEP) b_all[tid] = breg;
         __syncthreads();
-        if (kt0 + KT < kloop) {
-            tile_load<HD, KT>(kreg, Kb, s.k_sr, kt0 + KT, s.Kn);
-            tile_load<HD, KT>(vreg, Vb, s.v_sr, kt0 + KT, s.Kn);
-            breg = load_bias(kt0 + KT);
+        if (kt0 + KSTEP < kloop) {
+            tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, kt0 + KSTEP, s.Kn);
+            tile_load<HD, KSTEP, NTH>(vreg, Vb, s.v_sr, kt0 + KSTEP, s.Kn);
+            breg = load_bias(kt0 + KSTEP);
         }
+        const int kbase = kt0 + grp * KT;
+        if (kbase >= kloop) continue;
+        const bool need_mask = (kbase + KT > kend) || (s.ilk_diag >= 0 && kbase + KT - 1 > qblk0 + qw * 32 + s.ilk_diag);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x16 sacc, pacc;
@@ -338,14 +413,24 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
                 bf16x8 vf = lds_row8(v_lds + (sub * 32 + r) * PV + (ks * 2 + hf) * 16);
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], pacc, 0, 0, 0);
             }
-            // dS^T = P^T * (dP^T - delta)
+            // P^T = exp2(logit2 - lse2);  dS^T = P^T * (dP^T - delta)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kl = sub * 32 + crow(i, hf);
-                const int key = kt0 + kl;
-                const bool vis = (key < kend) && (s.ilk_diag < 0 || key <= q + s.ilk_diag);
-                const float p = vis ? __expf(sacc[i] * s.scale + b_lds[kl] - my_lse) : 0.f;
-                sacc[i] = p * (pacc[i] - my_delta);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *(const f32x4*)(b_lds + sub * 32 + 8 * g + 4 * hf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = g * 4 + j;
+                    float p = __builtin_amdgcn_exp2f(sacc[i] * scale2 + bb[j] - my_lse2);
+                    sacc[i] = p * (pacc[i] - my_delta);
+                }
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kbase + sub * 32 + crow(i, hf);
+                    const bool vis = (key < kend) && (s.ilk_diag < 0 || key <= q + s.ilk_diag);
+                    sacc[i] = vis ? sacc[i] : 0.f;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -360,6 +445,23 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
                 }
             }
         }
+    }
+    if constexpr (NG > 1) {
+        float* mrg = (float*)dq_smem;
+        const int slot = qw * 64 + lane;
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = dq[nt][i];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dq[nt][i] += mrg[(nt * 16 + i) * 256 + slot];
     }
     if (q < s.L) {
         __bf16* drow = dQ + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)q * s.q_sr;
@@ -376,31 +478,47 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dq_kernel(
 }
 
 // ============================================================================================ dK, dV, dbias
-constexpr int KB = 128;   // keys per workgroup (32 per wave)
+// One workgroup = 128 keys of one (batch, head): NG groups of 4 waves, one wave = 32 keys with dK^T, dV^T in
+// its accumulators.  K/V (128 keys) and a whole 128-query block of Q, dO, LSE, delta are resident in LDS, so
+// the slice loop runs without barriers; with NG = 2 the two groups take alternate 32-query slices of the SAME
+// keys and their dK^T / dV^T / dbias partial sums are added through LDS at the end.
+constexpr int KB = 128;   // keys per workgroup (32 per wave of a group)
 constexpr int QS = 32;    // query rows per slice
+constexpr int QBLK = 128; // query rows resident in LDS
 
 template <int HD>
-__global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(
+struct DkvLds {
+    static constexpr int PR = Pitch<HD>::ROW, PT = Pitch<HD>::TR;
+    static constexpr int KV_BYTES = 2 * KB * PR, QG_BYTES = 2 * QBLK * PT, ST_BYTES = 2 * QBLK * 4;
+    static constexpr int MERGE_BYTES = (HD / 32) * 16 * 256 * 4;      // one of dK^T / dV^T at a time
+    static constexpr int BYTES = KV_BYTES + QG_BYTES + ST_BYTES;
+    static_assert(MERGE_BYTES + 1024 <= BYTES, "merge buffer must fit in the tile area");
+};
+
+template <int HD, int NG>
+__global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dK,
     __bf16* __restrict__ dV, float* __restrict__ dbias_part) {
+    constexpr int NTH = NG * 256;
     constexpr int PR = Pitch<HD>::ROW;  // K, V tiles: row reads
-    constexpr int PT = Pitch<HD>::TR;   // Q, dO slices: row reads + transposed reads
+    constexpr int PT = Pitch<HD>::TR;   // Q, dO block: row reads + transposed reads
     constexpr int KS = HD / 16, NT = HD / 32;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* k_lds = smem;                       // [KB][PR]
     uint8_t* v_lds = k_lds + KB * PR;            // [KB][PR]
-    uint8_t* q_lds = v_lds + KB * PR;            // [QS][PT]
-    uint8_t* g_lds = q_lds + QS * PT;            // [QS][PT]
-    float* lse_lds = (float*)(g_lds + QS * PT);  // [QS]
-    float* del_lds = lse_lds + QS;               // [QS]
+    uint8_t* q_lds = v_lds + KB * PR;            // [QBLK][PT]
+    uint8_t* g_lds = q_lds + QBLK * PT;          // [QBLK][PT]
+    float* lse_lds = (float*)(g_lds + QBLK * PT);  // [QBLK]  (log2 domain)
+    float* del_lds = lse_lds + QBLK;             // [QBLK]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = wid >> 2, kw = wid & 3;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kb0 = blockIdx.x * KB;
-    const int key = kb0 + wid * 32 + r;          // this lane's key
+    const int key = kb0 + kw * 32 + r;           // this lane's key
 
     const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
     const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
@@ -410,15 +528,10 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     const bool key_ok = key < kend;
-    const float my_bias = (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
-
-    {
-        TileRegs<HD, KB> kreg, vreg;
-        tile_load<HD, KB>(kreg, Kb, s.k_sr, kb0, s.Kn);
-        tile_load<HD, KB>(vreg, Vb, s.v_sr, kb0, s.Kn);
-        tile_store<HD, KB>(kreg, k_lds, PR);
-        tile_store<HD, KB>(vreg, v_lds, PR);
-    }
+    float my_bias2 = 0.f;
+    if (bias && key < s.bias_len) my_bias2 = bias[(int64_t)b * s.bias_len + key] * LOG2E;
+    const float scale2 = s.scale * LOG2E;
+    const bool wg_live = kb0 < kend;
 
     f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -427,72 +540,129 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_bwd_dkv_kernel(
         for (int i = 0; i < 16; ++i) { dk[nt][i] = 0.f; dv[nt][i] = 0.f; }
     float db = 0.f;
 
-    // with the ILK mask key j is seen only by queries i >= j - diag: skip the slices before that
-    int q_begin = 0;
-    if (s.ilk_diag >= 0) q_begin = max(0, (kb0 - s.ilk_diag) / QS * QS);
-    const bool wg_live = kb0 < kend;
+    if (wg_live) {
+        TileRegs<HD, KB, NTH> kreg, vreg;
+        tile_load<HD, KB, NTH>(kreg, Kb, s.k_sr, kb0, s.Kn);
+        tile_load<HD, KB, NTH>(vreg, Vb, s.v_sr, kb0, s.Kn);
+        tile_store<HD, KB, NTH>(kreg, k_lds, PR);
+        tile_store<HD, KB, NTH>(vreg, v_lds, PR);
+    }
+    // with the ILK mask key j is seen only by queries i >= j - diag: skip the query blocks before that
+    int qb_begin = 0;
+    if (s.ilk_diag >= 0) qb_begin = max(0, (kb0 - s.ilk_diag) / QBLK * QBLK);
 
-    TileRegs<HD, QS> qreg, greg;
-    float lreg = 0.f, dreg = 0.f;
-    auto load_slice = [&](int q0) {
-        tile_load<HD, QS>(qreg, Qb, s.q_sr, q0, s.L);
-        tile_load<HD, QS>(greg, dOb, s.o_sr, q0, s.L);
-        const int qq = min(q0 + (tid & (QS - 1)), s.L - 1);
-        lreg = lse[((int64_t)b * s.h + h) * s.L + qq];
-        dreg = delta[((int64_t)b * s.h + h) * s.L + qq];
-    };
-    if (wg_live && q_begin < s.L) load_slice(q_begin);
-    for (int q0 = q_begin; wg_live && q0 < s.L; q0 += QS) {
-        __syncthreads();
-        tile_store<HD, QS>(qreg, q_lds, PT);
-        tile_store<HD, QS>(greg, g_lds, PT);
-        if (tid < QS) {
-            lse_lds[tid] = lreg;
-            del_lds[tid] = dreg;
-        }
-        __syncthreads();
-        if (q0 + QS < s.L) load_slice(q0 + QS);
-        // S[q][key] = Q K^T and dP[q][key] = dO V^T  (key on the lane)
-        f32x16 sacc, pacc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 qa = lds_row8(q_lds + r * PT + (ks * 2 + hf) * 16);
-            bf16x8 kf = lds_row8(k_lds + (wid * 32 + r) * PR + (ks * 2 + hf) * 16);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf, sacc, 0, 0, 0);
-            bf16x8 ga = lds_row8(g_lds + r * PT + (ks * 2 + hf) * 16);
-            bf16x8 vf = lds_row8(v_lds + (wid * 32 + r) * PR + (ks * 2 + hf) * 16);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf, pacc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ql = crow(i, hf);
-            const int qq = q0 + ql;
-            const bool vis = key_ok && (qq < s.L) && (s.ilk_diag < 0 || key <= qq + s.ilk_diag);
-            const float p = vis ? __expf(sacc[i] * s.scale + my_bias - lse_lds[ql]) : 0.f;
-            const float ds = p * (pacc[i] - del_lds[ql]);
-            sacc[i] = p;
-            pacc[i] = ds;
-            db += ds;
-        }
-        // dV^T[n][key] += sum_q dO[q][n] P[q][key];  dK^T[n][key] += sum_q Q[q][n] dS[q][key]
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = pack8(sacc, s2);
-            const bf16x8 df = pack8(pacc, s2);
-            const int qrow = s2 * 16 + 4 * hf + ((lane & 15) >> 2);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = nt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-                const uint8_t* g0 = g_lds + qrow * PT + col * 2;
-                bf16x8 gt = lds_tr8(g0, g0 + 8 * PT);
-                dv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[nt], 0, 0, 0);
-                const uint8_t* q0p = q_lds + qrow * PT + col * 2;
-                bf16x8 qt = lds_tr8(q0p, q0p + 8 * PT);
-                dk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, df, dk[nt], 0, 0, 0);
+    for (int qb0 = qb_begin; wg_live && qb0 < s.L; qb0 += QBLK) {
+        __syncthreads();                         // previous block fully consumed (no-op cost on the first pass)
+        {
+            TileRegs<HD, QBLK, NTH> qreg, greg;
+            tile_load<HD, QBLK, NTH>(qreg, Qb, s.q_sr, qb0, s.L);
+            tile_load<HD, QBLK, NTH>(greg, dOb, s.o_sr, qb0, s.L);
+            float lreg = 0.f, dreg = 0.f;
+            if (tid < QBLK) {
+                const int qq = min(qb0 + tid, s.L - 1);
+                lreg = lse[((int64_t)b * s.h + h) * s.L + qq] * LOG2E;
+                dreg = delta[((int64_t)b * s.h + h) * s.L + qq];
+            }
+            tile_store<HD, QBLK, NTH>(qreg, q_lds, PT);
+            tile_store<HD, QBLK, NTH>(greg, g_lds, PT);
+            if (tid < QBLK) {
+                lse_lds[tid] = lreg;
+                del_lds[tid] = dreg;
             }
         }
+        __syncthreads();
+        const int nslices = (min(QBLK, s.L - qb0) + QS - 1) / QS;
+        for (int sl = grp; sl < nslices; sl += NG) {
+            const int q0 = qb0 + sl * QS;
+            if (s.ilk_diag >= 0 && kb0 + kw * 32 > q0 + QS - 1 + s.ilk_diag) continue;   // wave sees nothing here
+            const uint8_t* qs_lds = q_lds + sl * QS * PT;
+            const uint8_t* gs_lds = g_lds + sl * QS * PT;
+            // S[q][key] = Q K^T and dP[q][key] = dO V^T  (key on the lane)
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 qa = lds_row8(qs_lds + r * PT + (ks * 2 + hf) * 16);
+                bf16x8 kf = lds_row8(k_lds + (kw * 32 + r) * PR + (ks * 2 + hf) * 16);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf, sacc, 0, 0, 0);
+                bf16x8 ga = lds_row8(gs_lds + r * PT + (ks * 2 + hf) * 16);
+                bf16x8 vf = lds_row8(v_lds + (kw * 32 + r) * PR + (ks * 2 + hf) * 16);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf, pacc, 0, 0, 0);
+            }
+            const bool need_mask = !key_ok || (q0 + QS > s.L) || (s.ilk_diag >= 0 && kb0 + kw * 32 + 31 > q0 + s.ilk_diag);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ll = *(const f32x4*)(lse_lds + sl * QS + 8 * g + 4 * hf);
+                const f32x4 dd = *(const f32x4*)(del_lds + sl * QS + 8 * g + 4 * hf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = g * 4 + j;
+                    float p = __builtin_amdgcn_exp2f(sacc[i] * scale2 + my_bias2 - ll[j]);
+                    if (need_mask) {
+                        const int qq = q0 + crow(i, hf);
+                        const bool vis = key_ok && (qq < s.L) && (s.ilk_diag < 0 || key <= qq + s.ilk_diag);
+                        p = vis ? p : 0.f;
+                    }
+                    const float ds = p * (pacc[i] - dd[j]);
+                    sacc[i] = p;
+                    pacc[i] = ds;
+                    db += ds;
+                }
+            }
+            // dV^T[n][key] += sum_q dO[q][n] P[q][key];  dK^T[n][key] += sum_q Q[q][n] dS[q][key]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(sacc, s2);
+                const bf16x8 df = pack8(pacc, s2);
+                const int qrow = s2 * 16 + 4 * hf + ((lane & 15) >> 2);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = nt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                    const uint8_t* g0 = gs_lds + qrow * PT + col * 2;
+                    bf16x8 gt = lds_tr8(g0, g0 + 8 * PT);
+                    dv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[nt], 0, 0, 0);
+                    const uint8_t* q0p = qs_lds + qrow * PT + col * 2;
+                    bf16x8 qt = lds_tr8(q0p, q0p + 8 * PT);
+                    dk[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, df, dk[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if constexpr (NG > 1) {
+        // add the second group's partial sums (same lane <-> same key / register layout)
+        float* mrg = (float*)smem;
+        const int slot = kw * 64 + lane;
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = dk[nt][i];
+            mrg[NT * 16 * 256 + slot] = db;
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dk[nt][i] += mrg[(nt * 16 + i) * 256 + slot];
+            db += mrg[NT * 16 * 256 + slot];
+        }
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = dv[nt][i];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dv[nt][i] += mrg[(nt * 16 + i) * 256 + slot];
     }
 
     if (key < s.Kn) {
@@ -570,17 +740,30 @@ static int check_shape(const star_xattn_shape* s, const char* who) {
     return STAR_OK;
 }
 
-template <int HD>
-static size_t dkv_lds_bytes() {
-    return (size_t)2 * KB * Pitch<HD>::ROW + (size_t)2 * QS * Pitch<HD>::TR + 2 * QS * sizeof(float);
+template <int HD, int NG>
+static int launch_fwd_ng(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
+                         const star_xattn_shape* s, void* o, float* lse, hipStream_t st) {
+    const int smem = FwdLds<HD, NG>::BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)xattn_fwd_kernel<HD, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+        set_error("star_xattn_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+        return STAR_ERR_LAUNCH;
+    }
+    dim3 grid(cdiv(s->L, 128), s->h, s->B);
+    hipLaunchKernelGGL((xattn_fwd_kernel<HD, NG>), grid, dim3(NG * 256), smem, st, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)v, bias, key_len, *s, (__bf16*)o, lse);
+    return STAR_OK;
 }
 
 template <int HD>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
                       const star_xattn_shape* s, void* o, float* lse, float* p_out, hipStream_t st) {
-    dim3 grid(cdiv(s->L, 128), s->h, s->B);
-    hipLaunchKernelGGL(xattn_fwd_kernel<HD>, grid, dim3(XA_THREADS), 0, st, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)v, bias, key_len, *s, (__bf16*)o, lse);
+    // more than one 64-key tile: split the keys over two wave groups (two waves per SIMD)
+    static const char* force = getenv("STAR_XA_NG");
+    const bool two = force ? (force[0] == '2') : (s->Kn > KT);
+    int rc = two ? launch_fwd_ng<HD, 2>(q, k, v, bias, key_len, s, o, lse, st)
+                 : launch_fwd_ng<HD, 1>(q, k, v, bias, key_len, s, o, lse, st);
+    if (rc) return rc;
     if (p_out) {
         const int64_t rows = (int64_t)s->B * s->h * s->L;
         hipLaunchKernelGGL(xattn_probs_kernel<HD>, dim3(cdiv(rows, 4)), dim3(XA_THREADS), 0, st, (const __bf16*)q,
@@ -589,26 +772,37 @@ static int launch_fwd(const void* q, const void* k, const void* v, const float* 
     return STAR_OK;
 }
 
+template <int HD, int NG>
+static int launch_bwd_ng(const void* q, const void* k, const void* v, const void* o, const void* do_,
+                         const float* lse, const float* bias, const int32_t* key_len, const star_xattn_shape* s,
+                         void* dq, void* dk, void* dv, float* delta, float* dbias_part, hipStream_t st) {
+    const int smem_dq = DqLds<HD, NG>::BYTES, smem_dkv = DkvLds<HD>::BYTES;
+    hipError_t e1 = hipFuncSetAttribute((const void*)xattn_bwd_dq_kernel<HD, NG>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
+    hipError_t e2 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_kernel<HD, NG>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error("star_xattn_bwd: cannot reserve %d / %d bytes of LDS", smem_dq, smem_dkv);
+        return STAR_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq, st,
+                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o, (const __bf16*)do_, lse,
+                       delta, bias, key_len, *s, (__bf16*)dq);
+    hipLaunchKernelGGL((xattn_bwd_dkv_kernel<HD, NG>), dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(NG * 256), smem_dkv, st,
+                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
+                       (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+    return STAR_OK;
+}
+
 template <int HD>
 static int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                       const float* bias, const int32_t* key_len, const star_xattn_shape* s, void* dq, void* dk,
                       void* dv, float* delta, float* dbias_part, float* dbias, int accumulate, hipStream_t st) {
-    const int64_t rows = (int64_t)s->B * s->h * s->L;
-    hipLaunchKernelGGL(xattn_delta_kernel<HD>, dim3(cdiv(rows, 4)), dim3(XA_THREADS), 0, st, (const __bf16*)o,
-                       (const __bf16*)do_, *s, delta);
-    hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3(cdiv(s->L, 128), s->h, s->B), dim3(XA_THREADS), 0, st,
-                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
-                       (const float*)delta, bias, key_len, *s, (__bf16*)dq);
-    const size_t smem = dkv_lds_bytes<HD>();
-    hipError_t e = hipFuncSetAttribute((const void*)xattn_bwd_dkv_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem);
-    if (e != hipSuccess) {
-        set_error("star_xattn_bwd: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
-        return STAR_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(xattn_bwd_dkv_kernel<HD>, dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(XA_THREADS), smem, st,
-                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
-                       (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+    static const char* force = getenv("STAR_XA_NG");
+    const bool two = force ? (force[0] == '2') : true;
+    int rc = two ? launch_bwd_ng<HD, 2>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st)
+                 : launch_bwd_ng<HD, 1>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st);
+    if (rc) return rc;
     if (dbias && s->bias_len > 0)
         hipLaunchKernelGGL(xattn_dbias_reduce_kernel, dim3(cdiv(s->bias_len, 256), s->B), dim3(256), 0, st,
                            (const float*)dbias_part, s->B, s->h, s->Kn, s->bias_len, accumulate, dbias);
