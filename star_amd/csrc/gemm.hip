@@ -12,22 +12,32 @@
 //   EPI_DH      G = ds[m]*w2[n]*(H>0) -> G, G^T (bf16) + column partials for dw2/db1   (backward 1)
 //   EPI_SLAB    fp32 split-K slab store                                      (dW1 = G^T X)
 //   EPI_ROWS    bf16 store with row scatter                                  (dX = G W1)
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 mfma_f32_16x16x32_bf16.
-// Operands are staged with global_load_lds (16 B/lane, LDS image lane-linear) into two LDS buffers;
-// the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the
-// per-lane SOURCE address and to the read address (same involution on both sides).
+// Tile 256x256x32, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
+// registers).  The large tile is what the kernel is built around: at 128x128 the L2 -> LDS operand traffic per
+// FLOP, not the MFMA rate, bounded it.  Operands are staged with global_load_lds (16 B/lane, LDS image
+// lane-linear) into a 4-stage ring (128 KiB) with ONE raw s_barrier per K tile and counted vmcnt, so two tiles of
+// loads stay in flight across every barrier; the XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free is applied to the per-lane SOURCE address and to the read address (same involution).
 // Workgroup -> tile mapping is XCD-aware: the column tiles of one row panel run on one XCD, so the
 // A panel is fetched into one L2 instead of eight.
 // Algorithmic work: forward 2*N_f*d*(d+1) FLOP; bytes: X 2*d*N_f + W1 2*d*d read, scores 4*N_f written.
 #include "common.h"
+#include <stdlib.h>
 
 namespace star {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int GEMM_THREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;           // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // double buffered: 64 KiB
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int GEMM_THREADS = 512;                 // 8 waves: 2 (M) x 4 (N), each 128 x 64
+constexpr int NWAVE = GEMM_THREADS / 64;
+constexpr int TM = 8, TN = 4;                     // 16x16 accumulator tiles per wave
+constexpr int ROW_BYTES = BK * 2;                 // 64-byte LDS rows
+constexpr int A_TILE_BYTES = BM * ROW_BYTES;      // 16 KiB
+constexpr int B_TILE_BYTES = BN * ROW_BYTES;      // 16 KiB
+constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+constexpr int NSTAGE = 4;                         // ring of K tiles: two tiles of loads stay in flight
+constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;    // 128 KiB -> one workgroup (2 waves/SIMD) per CU
+constexpr int A_PIECES = BM / 16 / NWAVE;         // 1-KiB global_load_lds pieces (16 rows) per wave per K tile: 2
+constexpr int B_PIECES = BN / 16 / NWAVE;         // 2
 
 enum { EPI_SCORE = 0, EPI_DH = 1, EPI_SLAB = 2, EPI_ROWS = 3 };
 
@@ -36,7 +46,7 @@ struct GemmParams {
     const __bf16* B;
     int64_t lda, ldb;
     int M, N;                 // logical sizes (rows of A / rows of B)
-    int kchunks;              // K / 64 in total
+    int kchunks;              // K / BK in total
     int splits;               // split-K factor (EPI_SLAB)
     const int32_t* a_rows;    // optional row gather for A (M entries), rows >= a_rows_n clamp to entry 0
     int a_rows_n;
@@ -62,143 +72,188 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS image of an operand tile: [rows][4 chunks of 16 B]; chunk c of row r is stored at position
+// c ^ swz(r), swz(r) = (-(r >> 2)) & 3.  With this involution the 16 lanes that one ds_read_b128 cycle serves
+// (rows 0-3,12-15 of k-chunk q together with rows 4-11 of k-chunk q+1) fall on 16 distinct 16-B slots of the
+// 256-B bank row.  global_load_lds writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE
+// address when staging and to the address when reading (the same involution on both sides).
+__device__ __forceinline__ int swz4(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid >> 2, wc = wid & 3;
 
-    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every
-    // XCD whole row panels so that all column tiles of a panel hit the same L2.
-    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD whole
+    // (row panel, K split) pairs so that all column tiles that share an A slab hit the same L2.
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
-    const int per_panel = nbn * p.splits;
-    const int m_tile = (local / per_panel) * 8 + xcd;
-    const int rem = local % per_panel;
-    const int n_tile = rem % nbn;
-    const int split = rem / nbn;
-    if (m_tile >= nbm) return;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int panel = (local / nbn) * 8 + xcd;
+    const int n_tile = local % nbn;
+    if (panel >= nbm * p.splits) return;
+    const int m_tile = panel % nbm, split = panel / nbm;
+    int m0 = m_tile * BM, n0 = n_tile * BN;
 
     const int cps = (p.kchunks + p.splits - 1) / p.splits;
     const int kc0 = split * cps;
     const int kc1 = min(p.kchunks, kc0 + cps);
     const int nk = max(0, kc1 - kc0);
 
-    // ---- per-lane staging sources.  Wave w issues 4 A pieces and 4 B pieces per K step; piece i
-    // covers tile rows (w*4+i)*8 .. +8, lane l -> row (l>>3), 16-B chunk (l&7) of the 128-B row.
-    const __bf16* asrc[4];
-    const __bf16* bsrc[4];
+    // ---- per-lane staging sources.  Piece j covers tile rows j*16 .. +16; lane l -> row (l>>2), position (l&3).
+    const __bf16* asrc[A_PIECES];
+    const __bf16* bsrc[B_PIECES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wid * 4 + i) * 8 + (lane >> 3);
-        const int swz = ((lane >> 4) + 4 * (i & 1)) & 7;       // == (row >> 1) & 7
-        const int chunk = (lane & 7) ^ swz;
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int row = (wid * A_PIECES + i) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
         int am = m0 + row;
         if (am >= p.M) am = p.M - 1;
         int64_t arow = am;
         if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
         asrc[i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
-        bsrc[i] = p.B + (int64_t)(n0 + row) * p.ldb + (int64_t)kc0 * BK + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int row = (wid * B_PIECES + i) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ swz4(row);
+        int bn = n0 + row;
+        if (bn >= p.N) bn = p.N - 1;
+        bsrc[i] = p.B + (int64_t)bn * p.ldb + (int64_t)kc0 * BK + chunk * 8;
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto stage = [&](int buf, int kt) {
-        uint8_t* base = lds + buf * STAGE_BYTES + (wid * 4) * 1024;
+        uint8_t* base = lds + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(asrc[i] + (int64_t)kt * BK, base + i * 1024);
+        for (int i = 0; i < A_PIECES; ++i) glds16(asrc[i] + (int64_t)kt * BK, base + (wid * A_PIECES + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(bsrc[i] + (int64_t)kt * BK, base + TILE_BYTES + i * 1024);
+        for (int i = 0; i < B_PIECES; ++i)
+            glds16(bsrc[i] + (int64_t)kt * BK, base + A_TILE_BYTES + (wid * B_PIECES + i) * 1024);
     };
 
-    // fragment read addresses: row r of a tile at r*128, chunk kc stored at position kc ^ ((r>>1)&7)
+    // fragment read: lane (frow = l&15, fq = l>>4) takes k-chunk fq of tile row (16*t + frow)
     const int frow = lane & 15;
-    const int fswz = frow >> 1;
     const int fq = lane >> 4;
+    const int foff = frow * ROW_BYTES + ((fq ^ swz4(frow)) << 4);    // swz4(16*t + frow) == swz4(frow)
 
-    if (nk > 0) stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const uint8_t* At = lds + (kt & 1) * STAGE_BYTES;
-        const uint8_t* Bt = At + TILE_BYTES;
+    // ---- 4-stage ring, ONE raw barrier per K tile, counted vmcnt (a __syncthreads() would drain the loads with
+    // vmcnt(0)).  Fragment reads are software-pipelined one tile ahead: in iteration kt the wave first issues the
+    // ds_reads of tile kt+1 into the other register set and then runs the 32 MFMAs of tile kt, so the LDS read
+    // burst of all 8 waves overlaps MFMA work instead of preceding it.
+    //   iteration kt: wait(tile kt+1 landed) -> barrier -> issue loads of tile kt+3 (its slot held tile kt-1,
+    //   whose fragments every wave consumed before this barrier) -> read frags kt+1 -> MFMA kt.
+    bf16x8 afA[TM], bfA[TN], afB[TM], bfB[TN];
+    auto read_frags = [&](int buf, bf16x8 (&af)[TM], bf16x8 (&bf)[TN]) {
+        const uint8_t* At = lds + buf * STAGE_BYTES + wr * (128 * ROW_BYTES) + foff;
+        const uint8_t* Bt = lds + buf * STAGE_BYTES + A_TILE_BYTES + wc * (64 * ROW_BYTES) + foff;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + fq) ^ fswz) << 4;
-            bf16x8 af[4], bfr[4];
+        for (int t = 0; t < TN; ++t) bf[t] = *(const bf16x8*)(Bt + t * 16 * ROW_BYTES);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *(const bf16x8*)(At + (wr * 64 + t * 16 + frow) * 128 + coff);
-                bfr[t] = *(const bf16x8*)(Bt + (wc * 64 + t * 16 + frow) * 128 + coff);
-            }
+        for (int t = 0; t < TM; ++t) af[t] = *(const bf16x8*)(At + t * 16 * ROW_BYTES);
+    };
+    auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bf)[TN]) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bfr[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one pipeline step: frags of tile kt are in (afc, bfc); fetch tile kt+1 into (afn, bfn)
+    auto step = [&](int kt, const bf16x8 (&afc)[TM], const bf16x8 (&bfc)[TN], bf16x8 (&afn)[TM], bf16x8 (&bfn)[TN]) {
+        // the current fragments were requested a whole MFMA block ago: retire them here (cheap), so that the
+        // compiler does not put an lgkmcnt(0) between the NEXT tile's ds_reads and this tile's MFMAs
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) only
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // tile kt+2 may still be in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
+            read_frags((kt + 1) & (NSTAGE - 1), afn, bfn);
         }
+        mma(afc, bfc);
+    };
+    if (nk > 0) stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 2) stage(2, 2);
+    if (nk > 0) {
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, afA, bfA);
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, afA, bfA, afB, bfB);
+        if (kt + 1 < nk) step(kt + 1, afB, bfB, afA, bfA);
     }
     __syncthreads();  // LDS is reused by the epilogues below
 
     // C layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + j
     const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
+    const int wrow0 = wr * 128, wcol0 = wc * 64;      // this wave's corner inside the tile
     float* red = (float*)lds;
 
     if constexpr (EPI == EPI_SCORE) {
-        float bb[4], ww[4];
+        float bb[TN], ww[TN];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wc * 64 + tn * 16 + ccol;
-            bb[tn] = p.b1[n];
-            ww[tn] = p.w2[n];
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wcol0 + tn * 16 + ccol;
+            bb[tn] = n < p.N ? p.b1[n] : 0.f;
+            ww[tn] = n < p.N ? p.w2[n] : 0.f;
         }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float s = 0.f;
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) s += fmaxf(acc[tm][tn][j] + bb[tn], 0.f) * ww[tn];
+                for (int tn = 0; tn < TN; ++tn) s += fmaxf(acc[tm][tn][j] + bb[tn], 0.f) * ww[tn];
                 // sum over the 16 lanes that share this row
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
                 s += __shfl_xor(s, 4, 64);
                 s += __shfl_xor(s, 8, 64);
-                if (ccol == 0) red[(wr * 64 + tm * 16 + crow4 + j) * 2 + wc] = s;
+                if (ccol == 0) red[(wrow0 + tm * 16 + crow4 + j) * 4 + wc] = s;
             }
         }
         __syncthreads();
-        if (tid < BM) p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = red[tid * 2] + red[tid * 2 + 1];
+        static_assert(BM <= GEMM_THREADS, "one thread per tile row");
+        if (tid < BM) {
+            const float* rr = red + tid * 4;
+            p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
+        }
     } else if constexpr (EPI == EPI_DH) {
-        float bb[4], ww[4], c_dw2[4], c_db1[4];
+        float bb[TN], ww[TN], c_dw2[TN], c_db1[TN];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wc * 64 + tn * 16 + ccol;
-            bb[tn] = p.b1[n];
-            ww[tn] = p.w2[n];
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wcol0 + tn * 16 + ccol;
+            bb[tn] = n < p.N ? p.b1[n] : 0.f;
+            ww[tn] = n < p.N ? p.w2[n] : 0.f;
             c_dw2[tn] = 0.f;
             c_db1[tn] = 0.f;
         }
         float ds_sum = 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
             float dsv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                const int m = m0 + wrow0 + tm * 16 + crow4 + j;
                 dsv[j] = (m < p.a_rows_n) ? p.ds[p.a_rows[m]] : 0.f;
                 ds_sum += dsv[j];
             }
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const int n = n0 + wc * 64 + tn * 16 + ccol;
+            for (int tn = 0; tn < TN; ++tn) {
+                const int n = n0 + wcol0 + tn * 16 + ccol;
                 bf16x4 gt;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -208,60 +263,61 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                     c_db1[tn] += g;
                     const __bf16 gb = (__bf16)g;
                     gt[j] = gb;
-                    const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
-                    p.G[(int64_t)m * p.N + n] = gb;
+                    const int m = m0 + wrow0 + tm * 16 + crow4 + j;
+                    if (n < p.N) p.G[(int64_t)m * p.N + n] = gb;
                 }
-                *(bf16x4*)(p.GT + (int64_t)n * p.ldgt + m0 + wr * 64 + tm * 16 + crow4) = gt;
+                if (n < p.N) *(bf16x4*)(p.GT + (int64_t)n * p.ldgt + m0 + wrow0 + tm * 16 + crow4) = gt;
             }
         }
-        // column sums over this wave's 64 rows: lanes with equal (lane & 15) hold the same column
+        // column sums over this wave's 128 rows: lanes with equal (lane & 15) hold the same column
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
+        for (int tn = 0; tn < TN; ++tn) {
             c_dw2[tn] += __shfl_xor(c_dw2[tn], 16, 64);
             c_dw2[tn] += __shfl_xor(c_dw2[tn], 32, 64);
             c_db1[tn] += __shfl_xor(c_db1[tn], 16, 64);
             c_db1[tn] += __shfl_xor(c_db1[tn], 32, 64);
             if (lane < 16) {
-                const int c = wc * 64 + tn * 16 + ccol;
+                const int c = wcol0 + tn * 16 + ccol;
                 red[(c * 2 + wr) * 2 + 0] = c_dw2[tn];
                 red[(c * 2 + wr) * 2 + 1] = c_db1[tn];
             }
         }
-        // db2 partial: sum of ds over this tile's 128 rows (lanes 0,16,32,48 hold 16 distinct rows each)
+        // db2 partial: sum of ds over this tile's 256 rows (lanes 0,16,32,48 hold distinct rows)
         ds_sum += __shfl_xor(ds_sum, 16, 64);
         ds_sum += __shfl_xor(ds_sum, 32, 64);
-        if (lane == 0 && wc == 0) red[512 + wr] = ds_sum;
+        if (lane == 0 && wc == 0) red[1024 + wr] = ds_sum;
         __syncthreads();
-        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red[512] + red[513];
-        if (tid < BN) {
+        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red[1024] + red[1025];
+        if (tid < BN && n0 + tid < p.N) {
             const int64_t o = (int64_t)m_tile * p.N + n0 + tid;
-            p.colpart[o] = red[(tid * 2 + 0) * 2 + 0] + red[(tid * 2 + 1) * 2 + 0];
-            p.colpart[(int64_t)nbm * p.N + o] = red[(tid * 2 + 0) * 2 + 1] + red[(tid * 2 + 1) * 2 + 1];
+            const float* rc = red + tid * 4;
+            p.colpart[o] = rc[0] + rc[2];
+            p.colpart[(int64_t)nbm * p.N + o] = rc[1] + rc[3];
         }
     } else if constexpr (EPI == EPI_SLAB) {
         float* slab = p.slab + (int64_t)split * p.M * p.N;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
-                    const int n = n0 + wc * 64 + tn * 16 + ccol;
-                    if (m < p.M) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
+                    const int m = m0 + wrow0 + tm * 16 + crow4 + j;
+                    const int n = n0 + wcol0 + tn * 16 + ccol;
+                    if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
                 }
     } else {  // EPI_ROWS
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = m0 + wr * 64 + tm * 16 + crow4 + j;
+                const int m = m0 + wrow0 + tm * 16 + crow4 + j;
                 if (m >= p.out_rows_n) continue;
                 const int64_t orow = p.out_rows[m];
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const int n = n0 + wc * 64 + tn * 16 + ccol;
-                    p.out[orow * p.ldo + n] = (__bf16)acc[tm][tn][j];
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = n0 + wcol0 + tn * 16 + ccol;
+                    if (n < p.N) p.out[orow * p.ldo + n] = (__bf16)acc[tm][tn][j];
                 }
             }
     }
@@ -358,8 +414,8 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
 }
 
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
-    const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-    const int grid = ((nbm + 7) / 8) * 8 * nbn * p.splits;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
     static bool attr_done[64] = {};
     int dev = 0;
     hipGetDevice(&dev);
@@ -383,7 +439,7 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int bwd_splits(int d) {
-    const int tiles = (d / BM) * (d / BN);
+    const int tiles = ((d + BM - 1) / BM) * ((d + BN - 1) / BN);
     int s = 512 / tiles;
     return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
@@ -393,7 +449,7 @@ static inline int bwd_splits(int d) {
 extern "C" size_t star_scorer_fwd_workspace(int64_t N, int d) {
     using namespace star;
     if (N <= 0 || d <= 0) return 0;
-    return align256((size_t)(d / BN) * (size_t)round_up(N, BM) * sizeof(float));
+    return align256((size_t)((d + BN - 1) / BN) * (size_t)round_up(N, BM) * sizeof(float));
 }
 
 extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
@@ -423,7 +479,7 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
     hipStream_t st = (hipStream_t)stream;
     launch_gemm(EPI_SCORE, p, st);
     hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
-                       p.partial_ld, d / BN, b2, N, scores);
+                       p.partial_ld, (d + BN - 1) / BN, b2, N, scores);
     STAR_LAUNCH_CHECK("star_scorer_fwd");
     return STAR_OK;
 }

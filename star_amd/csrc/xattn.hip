@@ -123,7 +123,8 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
     uint8_t* v_all = k_all + FwdLds<HD, NG>::K_BYTES;
     float* b_all = (float*)(v_all + FwdLds<HD, NG>::V_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform
     const int grp = wid >> 2, qw = wid & 3;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
     uint8_t* v_all = k_all + DqLds<HD, NG>::K_BYTES;
     float* b_all = (float*)(v_all + DqLds<HD, NG>::V_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform
     const int grp = wid >> 2, qw = wid & 3;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -478,60 +480,76 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
 }
 
 // ============================================================================================ dK, dV, dbias
-// One workgroup = 128 keys of one (batch, head): NG groups of 4 waves, one wave = 32 keys with dK^T, dV^T in
-// its accumulators.  K/V (128 keys) and a whole 128-query block of Q, dO, LSE, delta are resident in LDS, so
-// the slice loop runs without barriers; with NG = 2 the two groups take alternate 32-query slices of the SAME
-// keys and their dK^T / dV^T / dbias partial sums are added through LDS at the end.
-constexpr int KB = 128;   // keys per workgroup (32 per wave of a group)
+constexpr int KB = 128;   // keys per workgroup (32 per wave)
 constexpr int QS = 32;    // query rows per slice
-constexpr int QBLK = 128; // query rows resident in LDS
 
+// General variant (any L, HD in {64, 96, 128}): one workgroup = 4 waves = 128 keys; every wave keeps the K (and,
+// for HD <= 96, V) MFMA fragments of its 32 keys in VGPRs, loaded straight from global memory, with dK^T, dV^T in
+// its accumulators, and walks all query slices of a query block staged in LDS (which the transposed reads need).
+// Two to three workgroups share a CU so that their load / compute / store phases overlap.
 template <int HD>
-struct DkvLds {
-    static constexpr int PR = Pitch<HD>::ROW, PT = Pitch<HD>::TR;
-    static constexpr int KV_BYTES = 2 * KB * PR, QG_BYTES = 2 * QBLK * PT, ST_BYTES = 2 * QBLK * 4;
-    static constexpr int MERGE_BYTES = (HD / 32) * 16 * 256 * 4;      // one of dK^T / dV^T at a time
-    static constexpr int BYTES = KV_BYTES + QG_BYTES + ST_BYTES;
-    static_assert(MERGE_BYTES + 1024 <= BYTES, "merge buffer must fit in the tile area");
+struct DkvRegLds {
+    static constexpr int PT = Pitch<HD>::TR;
+    static constexpr int QB = (HD > 96) ? 64 : 128;              // query rows resident in LDS
+    static constexpr bool V_LDS = HD > 96;                       // HD = 128: V stays in LDS (register budget)
+    static constexpr int V_BYTES = V_LDS ? KB * Pitch<HD>::ROW : 0;
+    static constexpr int BYTES = 2 * QB * PT + 2 * QB * 4 + V_BYTES;
 };
 
-template <int HD, int NG>
-__global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
+template <int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void xattn_bwd_dkv_reg_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dK,
     __bf16* __restrict__ dV, float* __restrict__ dbias_part) {
-    constexpr int NTH = NG * 256;
-    constexpr int PR = Pitch<HD>::ROW;  // K, V tiles: row reads
-    constexpr int PT = Pitch<HD>::TR;   // Q, dO block: row reads + transposed reads
+    constexpr int NTH = 256, QBLK = DkvRegLds<HD>::QB;
+    constexpr int PT = Pitch<HD>::TR;
     constexpr int KS = HD / 16, NT = HD / 32;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* k_lds = smem;                       // [KB][PR]
-    uint8_t* v_lds = k_lds + KB * PR;            // [KB][PR]
-    uint8_t* q_lds = v_lds + KB * PR;            // [QBLK][PT]
+    uint8_t* q_lds = smem;                       // [QBLK][PT]
     uint8_t* g_lds = q_lds + QBLK * PT;          // [QBLK][PT]
     float* lse_lds = (float*)(g_lds + QBLK * PT);  // [QBLK]  (log2 domain)
     float* del_lds = lse_lds + QBLK;             // [QBLK]
+    uint8_t* v_lds = (uint8_t*)(del_lds + QBLK); // [KB][PR] (only if V_LDS)
+    constexpr bool V_LDS = DkvRegLds<HD>::V_LDS;
+    constexpr int PR = Pitch<HD>::ROW;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int grp = wid >> 2, kw = wid & 3;
+    const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kb0 = blockIdx.x * KB;
     const int key = kb0 + kw * 32 + r;           // this lane's key
 
     const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
-    const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
-    const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
     const __bf16* dOb = dO + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
 
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     const bool key_ok = key < kend;
+    const bool wg_live = kb0 < kend;
+    const float scale2 = s.scale * LOG2E;
+
+    // K / V fragments of this lane's key (rows past Kn are clamped: their probabilities are masked to 0)
+    bf16x8 kfr[KS], vfr[V_LDS ? 1 : KS];
+    {
+        const int kk = min(key, s.Kn - 1);
+        const __bf16* krow = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh + (int64_t)kk * s.k_sr;
+        const __bf16* vrow = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh + (int64_t)kk * s.v_sr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kfr[ks] = *(const bf16x8*)(krow + (ks * 2 + hf) * 8);
+            if constexpr (!V_LDS) vfr[ks] = *(const bf16x8*)(vrow + (ks * 2 + hf) * 8);
+        }
+        if constexpr (V_LDS) {
+            if (wg_live) {
+                TileRegs<HD, KB, NTH> vreg;
+                tile_load<HD, KB, NTH>(vreg, V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh, s.v_sr, kb0, s.Kn);
+                tile_store<HD, KB, NTH>(vreg, v_lds, PR);
+            }
+        }
+    }
     float my_bias2 = 0.f;
     if (bias && key < s.bias_len) my_bias2 = bias[(int64_t)b * s.bias_len + key] * LOG2E;
-    const float scale2 = s.scale * LOG2E;
-    const bool wg_live = kb0 < kend;
 
     f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -540,19 +558,12 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
         for (int i = 0; i < 16; ++i) { dk[nt][i] = 0.f; dv[nt][i] = 0.f; }
     float db = 0.f;
 
-    if (wg_live) {
-        TileRegs<HD, KB, NTH> kreg, vreg;
-        tile_load<HD, KB, NTH>(kreg, Kb, s.k_sr, kb0, s.Kn);
-        tile_load<HD, KB, NTH>(vreg, Vb, s.v_sr, kb0, s.Kn);
-        tile_store<HD, KB, NTH>(kreg, k_lds, PR);
-        tile_store<HD, KB, NTH>(vreg, v_lds, PR);
-    }
     // with the ILK mask key j is seen only by queries i >= j - diag: skip the query blocks before that
     int qb_begin = 0;
     if (s.ilk_diag >= 0) qb_begin = max(0, (kb0 - s.ilk_diag) / QBLK * QBLK);
 
     for (int qb0 = qb_begin; wg_live && qb0 < s.L; qb0 += QBLK) {
-        __syncthreads();                         // previous block fully consumed (no-op cost on the first pass)
+        if (qb0 != qb_begin) __syncthreads();    // previous block fully consumed
         {
             TileRegs<HD, QBLK, NTH> qreg, greg;
             tile_load<HD, QBLK, NTH>(qreg, Qb, s.q_sr, qb0, s.L);
@@ -572,22 +583,22 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
         }
         __syncthreads();
         const int nslices = (min(QBLK, s.L - qb0) + QS - 1) / QS;
-        for (int sl = grp; sl < nslices; sl += NG) {
+        for (int sl = 0; sl < nslices; ++sl) {
             const int q0 = qb0 + sl * QS;
             if (s.ilk_diag >= 0 && kb0 + kw * 32 > q0 + QS - 1 + s.ilk_diag) continue;   // wave sees nothing here
             const uint8_t* qs_lds = q_lds + sl * QS * PT;
             const uint8_t* gs_lds = g_lds + sl * QS * PT;
-            // S[q][key] = Q K^T and dP[q][key] = dO V^T  (key on the lane)
             f32x16 sacc, pacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { sacc[i] = 0.f; pacc[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 qa = lds_row8(qs_lds + r * PT + (ks * 2 + hf) * 16);
-                bf16x8 kf = lds_row8(k_lds + (kw * 32 + r) * PR + (ks * 2 + hf) * 16);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kfr[ks], sacc, 0, 0, 0);
                 bf16x8 ga = lds_row8(gs_lds + r * PT + (ks * 2 + hf) * 16);
-                bf16x8 vf = lds_row8(v_lds + (kw * 32 + r) * PR + (ks * 2 + hf) * 16);
+                bf16x8 vf;
+                if constexpr (V_LDS) vf = lds_row8(v_lds + (kw * 32 + r) * PR + (ks * 2 + hf) * 16);
+                else vf = vfr[ks];
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf, pacc, 0, 0, 0);
             }
             const bool need_mask = !key_ok || (q0 + QS > s.L) || (s.ilk_diag >= 0 && kb0 + kw * 32 + 31 > q0 + s.ilk_diag);
@@ -610,7 +621,6 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
                     db += ds;
                 }
             }
-            // dV^T[n][key] += sum_q dO[q][n] P[q][key];  dK^T[n][key] += sum_q Q[q][n] dS[q][key]
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(sacc, s2);
@@ -628,41 +638,6 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
                 }
             }
         }
-    }
-
-    if constexpr (NG > 1) {
-        // add the second group's partial sums (same lane <-> same key / register layout)
-        float* mrg = (float*)smem;
-        const int slot = kw * 64 + lane;
-        __syncthreads();
-        if (grp == 1) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = dk[nt][i];
-            mrg[NT * 16 * 256 + slot] = db;
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dk[nt][i] += mrg[(nt * 16 + i) * 256 + slot];
-            db += mrg[NT * 16 * 256 + slot];
-        }
-        __syncthreads();
-        if (grp == 1) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mrg[(nt * 16 + i) * 256 + slot] = dv[nt][i];
-        }
-        __syncthreads();
-        if (grp == 1) return;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dv[nt][i] += mrg[(nt * 16 + i) * 256 + slot];
     }
 
     if (key < s.Kn) {
@@ -684,6 +659,247 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dkv_kernel(
     }
     db += __shfl_xor(db, 32, 64);
     if (dbias_part && hf == 0 && key < s.Kn) dbias_part[((int64_t)b * s.h + h) * s.Kn + key] = db;
+}
+
+// Short-target variant (L <= 128, HD = 64 or 128): the whole Q / dO / LSE / delta block of one (batch, head) is
+// staged ONCE into LDS (XOR-swizzled, unpadded) and then every wave walks its own 16-key groups on its own,
+// without a single barrier: K / V fragments of the NEXT group are prefetched into registers while the current
+// group is being computed (16x16x32 MFMAs, keys on the MFMA column), and the dK / dV stores of the previous
+// group drain behind the next group's arithmetic.  Load, compute and store phases therefore overlap inside a
+// wave instead of relying on co-resident workgroups.
+template <int HD>
+struct DkvSmall {
+    static constexpr int QROWS = 128;
+    static constexpr int ROWB = HD * 2;
+    static constexpr int BYTES = 2 * QROWS * ROWB + 2 * QROWS * 4;
+    static constexpr int WAVES = 8;
+    // 16-byte chunk swizzle of row r: conflict-free for the b128 row reads (lane groups of the 16x16x32 A operand)
+    // and for the transposed b64 reads (8 rows x 32 B per half wave)
+    __device__ static __forceinline__ int swz(int r) {
+        if constexpr (HD == 128) return (r & 7) << 1;
+        else return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 2) & 1);
+    }
+};
+
+template <int HD>
+__global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
+    const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
+    const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
+    const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dK,
+    __bf16* __restrict__ dV, float* __restrict__ dbias_part) {
+    using C = DkvSmall<HD>;
+    constexpr int NTH = 512, QROWS = C::QROWS, ROWB = C::ROWB;
+    constexpr int KS = HD / 32;       // k-steps of a 16x16x32 MFMA over the head dim
+    constexpr int NT = HD / 16;       // 16-wide head-dim tiles of dK^T / dV^T
+    constexpr int CPR = HD / 8;       // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* q_lds = smem;                          // [128][ROWB] swizzled
+    uint8_t* g_lds = q_lds + QROWS * ROWB;          // [128][ROWB] swizzled
+    float* lse_lds = (float*)(g_lds + QROWS * ROWB);  // [128] (log2 domain)
+    float* del_lds = lse_lds + QROWS;               // [128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: group loops and mask tests on SALU
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+
+    const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
+    const __bf16* dOb = dO + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
+    const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+    const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+    __bf16* dKb = dK + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+    __bf16* dVb = dV + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+
+    int kend = s.Kn;
+    if (key_len) kend = min(kend, key_len[b]);
+    const float scale2 = s.scale * LOG2E;
+
+    const int ngroups = (s.Kn + 15) >> 4;
+    const int gstride = gridDim.x * C::WAVES;
+    int grp = blockIdx.x * C::WAVES + wid;
+
+    // first group's K / V fragments: issued before the Q / dO staging so that both are in flight together
+    bf16x8 kfr[KS], vfr[KS];
+    float bias_cur = 0.f;
+    {
+        const int key = min(grp * 16 + r16, s.Kn - 1);
+        const __bf16* krow = Kb + (int64_t)key * s.k_sr + g * 8;
+        const __bf16* vrow = Vb + (int64_t)key * s.v_sr + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kfr[ks] = *(const bf16x8*)(krow + ks * 32);
+            vfr[ks] = *(const bf16x8*)(vrow + ks * 32);
+        }
+        if (bias && key < s.bias_len) bias_cur = bias[(int64_t)b * s.bias_len + key];
+    }
+    {
+        TileRegs<HD, QROWS, NTH> qreg, greg;
+        tile_load<HD, QROWS, NTH>(qreg, Qb, s.q_sr, 0, s.L);
+        tile_load<HD, QROWS, NTH>(greg, dOb, s.o_sr, 0, s.L);
+        float lreg = 0.f, dreg = 0.f;
+        if (tid < QROWS) {
+            const int qq = min(tid, s.L - 1);
+            lreg = lse[((int64_t)b * s.h + h) * s.L + qq] * LOG2E;
+            dreg = delta[((int64_t)b * s.h + h) * s.L + qq];
+        }
+#pragma unroll
+        for (int i = 0; i < TileRegs<HD, QROWS, NTH>::N; ++i) {
+            const int c = tid + i * NTH;
+            const int row = c / CPR, ch = c % CPR;
+            const int off = row * ROWB + ((ch ^ C::swz(row & 15)) << 4);
+            *(u32x4*)(q_lds + off) = qreg.v[i];
+            *(u32x4*)(g_lds + off) = greg.v[i];
+        }
+        if (tid < QROWS) {
+            lse_lds[tid] = lreg;
+            del_lds[tid] = dreg;
+        }
+    }
+    __syncthreads();          // the only barrier: from here on the waves run independently
+
+    const int nslices = (s.L + 31) >> 5;
+    // per-lane LDS offsets that do not depend on the group
+    const int sw_row = C::swz(r16);                               // row reads: row = 16t + r16
+    const int tr_row = 4 * g + (r16 >> 2);                        // transposed reads: row within the slice
+    const int sw_tr = C::swz(tr_row);                             // (row & 15) is the same for row and row + 16
+
+    for (; grp < ngroups; grp += gstride) {
+        const int key = grp * 16 + r16;
+        const bool key_ok = key < kend;
+        const float my_bias2 = bias_cur * LOG2E;
+        // smallest query that sees this lane's key (INT_MAX: key masked out altogether)
+        const int qmin = key_ok ? (s.ilk_diag >= 0 ? key - s.ilk_diag : -(1 << 30)) : 0x7fffffff;
+        // prefetch the next group's fragments
+        bf16x8 kn[KS], vn[KS];
+        float bias_nxt = 0.f;
+        {
+            const int ng = grp + gstride;
+            const int nkey = min((ng < ngroups ? ng : grp) * 16 + r16, s.Kn - 1);
+            const __bf16* krow = Kb + (int64_t)nkey * s.k_sr + g * 8;
+            const __bf16* vrow = Vb + (int64_t)nkey * s.v_sr + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kn[ks] = *(const bf16x8*)(krow + ks * 32);
+                vn[ks] = *(const bf16x8*)(vrow + ks * 32);
+            }
+            if (bias && nkey < s.bias_len) bias_nxt = bias[(int64_t)b * s.bias_len + nkey];
+        }
+
+        f32x4 dk[NT], dv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dk[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        float db = 0.f;
+
+        if (grp * 16 < kend) {
+#pragma unroll 1
+            for (int sl = 0; sl < nslices; ++sl) {
+                const int q0 = sl * 32;
+                if (s.ilk_diag >= 0 && grp * 16 > q0 + 31 + s.ilk_diag) continue;      // nothing visible (uniform)
+                // S[q][key], dP[q][key] for two 16-query tiles (key on the lane, 4 queries per tile in registers):
+                // all sixteen A fragments are requested before the first MFMA
+                bf16x8 qa[2][KS], ga[2][KS];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int rowoff = (q0 + 16 * t + r16) * ROWB;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int off = rowoff + (((4 * ks + g) ^ sw_row) << 4);
+                        qa[t][ks] = lds_row8(q_lds + off);
+                        ga[t][ks] = lds_row8(g_lds + off);
+                    }
+                }
+                f32x4 ll[2], dd[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ll[t] = *(const f32x4*)(lse_lds + q0 + 16 * t + 4 * g);
+                    dd[t] = *(const f32x4*)(del_lds + q0 + 16 * t + 4 * g);
+                }
+                f32x4 sacc[2], pacc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t][ks], kfr[ks], sacc[t], 0, 0, 0);
+                        pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[t][ks], vfr[ks], pacc[t], 0, 0, 0);
+                    }
+                // first half of the transposed fragments: in flight during the softmax arithmetic
+                const int trbase = (q0 + tr_row) * ROWB + 8 * (lane & 1);
+                bf16x8 gt[NT / 2], qt[NT / 2];
+#pragma unroll
+                for (int nt = 0; nt < NT / 2; ++nt) {
+                    const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                    gt[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
+                    qt[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
+                }
+                // visibility of (query, key): key valid, query < L, key <= query + diag  <=>  qmin <= query < L
+                bf16x8 pf, df;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int qq = q0 + 16 * t + 4 * g + j;
+                        float p = __builtin_amdgcn_exp2f(sacc[t][j] * scale2 + my_bias2 - ll[t][j]);
+                        p = (qq >= qmin && qq < s.L) ? p : 0.f;
+                        const float ds = p * (pacc[t][j] - dd[t][j]);
+                        db += ds;
+                        pf[4 * t + j] = (__bf16)p;
+                        df[4 * t + j] = (__bf16)ds;
+                    }
+                // dV^T[n][key] += sum_q dO[q][n] P[q][key];  dK^T[n][key] += sum_q Q[q][n] dS[q][key]
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    bf16x8 gt2[NT / 2], qt2[NT / 2];
+                    if (hlf == 0) {
+#pragma unroll
+                        for (int nt = 0; nt < NT / 2; ++nt) {
+                            const int off = trbase + (((2 * (nt + NT / 2) + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                            gt2[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
+                            qt2[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
+                        }
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT / 2; ++nt) {
+                        dv[nt + hlf * (NT / 2)] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt[nt], pf, dv[nt + hlf * (NT / 2)], 0, 0, 0);
+                        dk[nt + hlf * (NT / 2)] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[nt], df, dk[nt + hlf * (NT / 2)], 0, 0, 0);
+                    }
+                    if (hlf == 0) {
+#pragma unroll
+                        for (int nt = 0; nt < NT / 2; ++nt) { gt[nt] = gt2[nt]; qt[nt] = qt2[nt]; }
+                    }
+                }
+            }
+        }
+
+        if (key < s.Kn) {
+            __bf16* dkrow = dKb + (int64_t)key * s.k_sr + 4 * g;
+            __bf16* dvrow = dVb + (int64_t)key * s.v_sr + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4 a, c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = (__bf16)(dk[nt][j] * s.scale);
+                    c[j] = (__bf16)dv[nt][j];
+                }
+                *(bf16x4*)(dkrow + nt * 16) = a;
+                *(bf16x4*)(dvrow + nt * 16) = c;
+            }
+        }
+        db += __shfl_xor(db, 16, 64);
+        db += __shfl_xor(db, 32, 64);
+        if (dbias_part && g == 0 && key < s.Kn) dbias_part[((int64_t)b * s.h + h) * s.Kn + key] = db;
+
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kfr[ks] = kn[ks]; vfr[ks] = vn[ks]; }
+        bias_cur = bias_nxt;
+    }
 }
 
 // dbias[b,j] (+)= sum_h dbias_part[b,h,j]   (fixed order over heads)
@@ -776,19 +992,46 @@ template <int HD, int NG>
 static int launch_bwd_ng(const void* q, const void* k, const void* v, const void* o, const void* do_,
                          const float* lse, const float* bias, const int32_t* key_len, const star_xattn_shape* s,
                          void* dq, void* dk, void* dv, float* delta, float* dbias_part, hipStream_t st) {
-    const int smem_dq = DqLds<HD, NG>::BYTES, smem_dkv = DkvLds<HD>::BYTES;
+    const int smem_dq = DqLds<HD, NG>::BYTES;
     hipError_t e1 = hipFuncSetAttribute((const void*)xattn_bwd_dq_kernel<HD, NG>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
-    hipError_t e2 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_kernel<HD, NG>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        set_error("star_xattn_bwd: cannot reserve %d / %d bytes of LDS", smem_dq, smem_dkv);
+    if (e1 != hipSuccess) {
+        set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_dq);
         return STAR_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq, st,
                        (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o, (const __bf16*)do_, lse,
                        delta, bias, key_len, *s, (__bf16*)dq);
-    hipLaunchKernelGGL((xattn_bwd_dkv_kernel<HD, NG>), dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(NG * 256), smem_dkv, st,
+    static const char* dkv_force = getenv("STAR_XA_DKV");      // "gen" = always the general variant (A/B runs)
+    if constexpr (HD == 64 || HD == 128) {
+        if (s->L <= DkvSmall<HD>::QROWS && !dkv_force) {
+            const int smem_s = DkvSmall<HD>::BYTES;
+            hipError_t e3 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_small_kernel<HD>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_s);
+            if (e3 != hipSuccess) {
+                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
+                return STAR_ERR_LAUNCH;
+            }
+            // one workgroup (8 independent waves) per (batch, head); split the key groups over more workgroups
+            // only when B*h alone cannot fill the chip
+            const int ngroups = cdiv(s->Kn, 16);
+            int nch = 1;
+            const int64_t bh = (int64_t)s->B * s->h;
+            if (bh < 192) nch = (int)min((int64_t)cdiv(ngroups, DkvSmall<HD>::WAVES), (256 + bh - 1) / bh);
+            hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD>), dim3(nch, s->h, s->B), dim3(512), smem_s, st,
+                               (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
+                               (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+            return STAR_OK;
+        }
+    }
+    const int smem_r = DkvRegLds<HD>::BYTES;
+    hipError_t e3 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_reg_kernel<HD>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_r);
+    if (e3 != hipSuccess) {
+        set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_r);
+        return STAR_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((xattn_bwd_dkv_reg_kernel<HD>), dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(256), smem_r, st,
                        (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
                        (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
     return STAR_OK;

@@ -43,7 +43,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b"star_topk_select" in L.star_last_error()
     rc = L.star_scorer_fwd(None, None, None, None, None, 10, 100, None, None, 0, None)
     assert rc == -1
-    assert L.star_scorer_fwd_workspace(48000, 1024) == 8 * 48000 * 4
+    assert L.star_scorer_fwd_workspace(48000, 1024) == 4 * 48128 * 4   # 4 column tiles x rows padded to 256
 
 
 def test_ops_refuse_cpu_tensors():

@@ -334,7 +334,11 @@ def test_xattn_golden(ops, name, use_key_len):
 
 @pytest.mark.parametrize("B,h,L,K,hd,ilk", [(2, 8, 128, 375, 128, False), (2, 4, 24, 63, 96, False),
                                             (1, 8, 227, 229, 128, True), (2, 2, 130, 200, 64, True),
-                                            (1, 2, 300, 750, 128, False)])
+                                            (1, 2, 300, 750, 128, False),
+                                            # L <= 128: barrier-free dK/dV kernel, one workgroup per (b, h) ...
+                                            (25, 8, 100, 77, 64, False), (24, 8, 128, 200, 128, True),
+                                            # ... and with the key groups split over several workgroups
+                                            (2, 2, 60, 200, 64, True), (1, 3, 128, 1000, 128, False)])
 def test_xattn_random_vs_oracle(ops, B, h, L, K, hd, ilk):
     g = torch.Generator().manual_seed(B * 7 + L + K + hd)
     q = torch.randn(B, h, L, hd, generator=g)

@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> "<counters>" <kernel-substring> -- <kbench args>   (one rocprofv3 --pmc pass)
 tag=$1; ctrs=$2; kern=$3; shift 4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -s KILL 120 rocprofv3 --pmc $ctrs -d gpurun_out/pmc_$tag -o $tag --output-format csv -- python3 tools/kbench.py --iters 2 "$@" > gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $ctrs -d gpurun_out/pmc_$tag -o $tag --output-format csv -- python3 ${PMC_PROG:-tools/kbench.py --iters 2} "$@" > gpurun_out/pmc_$tag.log 2>&1
 echo exit $?
 python3 - <<PY
 import csv, collections
