@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "libstar_nugget.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file extras (STAR_XATTN_FLAGS etc. override for experiments)
 EXTRA = {"xattn.hip": os.environ.get("STAR_XATTN_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form=1").split(),
-         "gemm.hip": os.environ.get("STAR_GEMM_FLAGS", "").split()}
+         "gemm.hip": os.environ.get("STAR_GEMM_FLAGS", "-fno-slp-vectorize").split()}
 
 
 def _newer(a, b):

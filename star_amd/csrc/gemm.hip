@@ -38,6 +38,13 @@ constexpr int NSTAGE = 4;                         // ring of K tiles: two tiles 
 constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;    // 128 KiB -> one workgroup (2 waves/SIMD) per CU
 constexpr int A_PIECES = BM / 16 / NWAVE;         // 1-KiB global_load_lds pieces (16 rows) per wave per K tile: 2
 constexpr int B_PIECES = BN / 16 / NWAVE;         // 2
+// epilogue staging (EPI_DH, EPI_ROWS): every wave parks its 128 x 64 bf16 output tile TRANSPOSED in LDS
+// ([64 n][128 m], pitch 272 B) so that global stores are 16 B per lane along whichever axis the consumer wants
+constexpr int EP_PITCH = 128 * 2 + 16;
+constexpr int EP_WAVE_BYTES = 64 * EP_PITCH;      // 17 KiB
+constexpr int EP_RED_OFF = NWAVE * EP_WAVE_BYTES; // reduction scratch behind the eight wave tiles
+constexpr int EPI_LDS = EP_RED_OFF + 8192;        // 144 KiB
+static_assert(EPI_LDS >= GEMM_LDS && EPI_LDS <= 160 * 1024, "epilogue staging must cover the ring and fit the CU");
 
 enum { EPI_SCORE = 0, EPI_DH = 1, EPI_SLAB = 2, EPI_ROWS = 3 };
 
@@ -79,10 +86,38 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // address when staging and to the address when reading (the same involution on both sides).
 __device__ __forceinline__ int swz4(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
+// rows of the wave's staged [n][m] tile -> GT[n][m] (16 B per lane, 256 B contiguous per row)
+__device__ __forceinline__ void ep_store_nrows(const uint8_t* W, __bf16* __restrict__ dstT, int64_t ld, int n_base,
+                                               int m_base, int n_limit, int lane) {
+    const int chunk = lane & 15;
+    const uint8_t* src = W + (lane >> 4) * EP_PITCH + chunk * 16;
+    __bf16* dst = dstT + (int64_t)(n_base + (lane >> 4)) * ld + m_base + chunk * 8;     // running pointer
+    const int rows_ok = n_limit - n_base - (lane >> 4);                                 // row it*4 valid iff < rows_ok
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const u32x4 v = *(const u32x4*)(src + it * 4 * EP_PITCH);
+        if (it * 4 < rows_ok) *(u32x4*)dst = v;
+        dst += 4 * ld;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// transposed read of the staged tile: lane (i = lane & 15, g = lane >> 4) gets, for m = mb*16 + i, the eight
+// consecutive n = nh*32 + 8g .. +7 (16 B), i.e. a piece of ROW m of the un-transposed tile
+__device__ __forceinline__ u32x4 ep_read_mrow(const uint8_t* W, int mb, int nh, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const uint8_t* p0 = W + (nh * 32 + 8 * g + (i >> 2)) * EP_PITCH + (mb * 16 + 4 * (i & 3)) * 2;
+    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p0));
+    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p0 + 4 * EP_PITCH));
+    bf16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *(u32x4*)&r;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform
     const int wr = wid >> 2, wc = wid & 3;
 
     // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD whole
@@ -176,11 +211,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // tile kt+2 may still be in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
+            // the two waves of a SIMD (wid and wid + 4, i.e. wr = 0 / 1) issue their LDS-DMA pieces at opposite
+            // ends of the step: a piece costs its wave 100+ issue cycles, during which the other wave's MFMAs run
+            if (wr == 0 && kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
             read_frags((kt + 1) & (NSTAGE - 1), afn, bfn);
         }
         mma(afc, bfc);
+        if (wr == 1 && kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
     };
+    // EPI_DH: the dscores of this tile's 256 rows are fetched by one thread per row while the main loop runs
+    float my_ds = 0.f;
+    if constexpr (EPI == EPI_DH) {
+        if (tid < BM && m0 + tid < p.a_rows_n) my_ds = p.ds[p.a_rows[m0 + tid]];
+    }
     if (nk > 0) stage(0, 0);
     if (nk > 1) stage(1, 1);
     if (nk > 2) stage(2, 2);
@@ -232,6 +275,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
         }
     } else if constexpr (EPI == EPI_DH) {
+        uint8_t* W = lds + wid * EP_WAVE_BYTES;
+        float* red2 = (float*)(lds + EP_RED_OFF);
+        float* dsl = red2 + 1280;                    // [256] dscores of the tile rows
+        if (tid < BM) dsl[tid] = my_ds;
+        __syncthreads();
         float bb[TN], ww[TN], c_dw2[TN], c_db1[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -244,16 +292,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         float ds_sum = 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            float dsv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + wrow0 + tm * 16 + crow4 + j;
-                dsv[j] = (m < p.a_rows_n) ? p.ds[p.a_rows[m]] : 0.f;
-                ds_sum += dsv[j];
-            }
+            const f32x4 dsv = *(const f32x4*)(dsl + wrow0 + tm * 16 + crow4);
+            ds_sum += (dsv[0] + dsv[1]) + (dsv[2] + dsv[3]);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const int n = n0 + wcol0 + tn * 16 + ccol;
                 bf16x4 gt;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -261,12 +303,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                     const float g = (h > 0.f) ? dsv[j] * ww[tn] : 0.f;
                     c_dw2[tn] += dsv[j] * fmaxf(h, 0.f);
                     c_db1[tn] += g;
-                    const __bf16 gb = (__bf16)g;
-                    gt[j] = gb;
-                    const int m = m0 + wrow0 + tm * 16 + crow4 + j;
-                    if (n < p.N) p.G[(int64_t)m * p.N + n] = gb;
+                    gt[j] = (__bf16)g;
                 }
-                if (n < p.N) *(bf16x4*)(p.GT + (int64_t)n * p.ldgt + m0 + wrow0 + tm * 16 + crow4) = gt;
+                *(bf16x4*)(W + (tn * 16 + ccol) * EP_PITCH + (tm * 16 + crow4) * 2) = gt;
+            }
+            // pin the running column sums here: without this the instruction scheduler sinks the whole chain of
+            // adds to the end of the epilogue and keeps (spills) every g and h value until then
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(c_dw2[tn]), "+v"(c_db1[tn]));
+        }
+        // the tile is wave-private: LDS operations of one wave complete in order, no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ep_store_nrows(W, p.GT, p.ldgt, n0 + wcol0, m0 + wrow0, p.N, lane);
+        if (n0 + wcol0 < p.N) {
+            __bf16* gdst = p.G + (int64_t)(m0 + wrow0 + (lane & 15)) * p.N + n0 + wcol0 + 8 * (lane >> 4);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) *(u32x4*)(gdst + nh * 32) = ep_read_mrow(W, mb, nh, lane);
+                gdst += (int64_t)16 * p.N;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // column sums over this wave's 128 rows: lanes with equal (lane & 15) hold the same column
@@ -278,19 +336,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             c_db1[tn] += __shfl_xor(c_db1[tn], 32, 64);
             if (lane < 16) {
                 const int c = wcol0 + tn * 16 + ccol;
-                red[(c * 2 + wr) * 2 + 0] = c_dw2[tn];
-                red[(c * 2 + wr) * 2 + 1] = c_db1[tn];
+                red2[(c * 2 + wr) * 2 + 0] = c_dw2[tn];
+                red2[(c * 2 + wr) * 2 + 1] = c_db1[tn];
             }
         }
         // db2 partial: sum of ds over this tile's 256 rows (lanes 0,16,32,48 hold distinct rows)
         ds_sum += __shfl_xor(ds_sum, 16, 64);
         ds_sum += __shfl_xor(ds_sum, 32, 64);
-        if (lane == 0 && wc == 0) red[1024 + wr] = ds_sum;
+        if (lane == 0 && wc == 0) red2[1024 + wr] = ds_sum;
         __syncthreads();
-        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red[1024] + red[1025];
+        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red2[1024] + red2[1025];
         if (tid < BN && n0 + tid < p.N) {
             const int64_t o = (int64_t)m_tile * p.N + n0 + tid;
-            const float* rc = red + tid * 4;
+            const float* rc = red2 + tid * 4;
             p.colpart[o] = rc[0] + rc[2];
             p.colpart[(int64_t)nbm * p.N + o] = rc[1] + rc[3];
         }
@@ -307,19 +365,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                     if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
                 }
     } else {  // EPI_ROWS
+        uint8_t* W = lds + wid * EP_WAVE_BYTES;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + wrow0 + tm * 16 + crow4 + j;
-                if (m >= p.out_rows_n) continue;
-                const int64_t orow = p.out_rows[m];
+            for (int tn = 0; tn < TN; ++tn) {
+                bf16x4 o;
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int n = n0 + wcol0 + tn * 16 + ccol;
-                    if (n < p.N) p.out[orow * p.ldo + n] = (__bf16)acc[tm][tn][j];
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[tm][tn][j];
+                *(bf16x4*)(W + (tn * 16 + ccol) * EP_PITCH + (tm * 16 + crow4) * 2) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (n0 + wcol0 < p.N) {
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const int m = m0 + wrow0 + mb * 16 + (lane & 15);
+                const bool ok = m < p.out_rows_n;
+                const int64_t orow = ok ? p.out_rows[m] : 0;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const u32x4 v = ep_read_mrow(W, mb, nh, lane);     // every lane takes part in the LDS read
+                    if (ok) *(u32x4*)(p.out + orow * p.ldo + n0 + wcol0 + nh * 32 + 8 * (lane >> 4)) = v;
                 }
             }
+        }
     }
 }
 
@@ -422,16 +493,16 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     dev &= 63;
     if (!attr_done[dev]) {
         hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_DH>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_DH>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
         hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
         attr_done[dev] = true;
     }
     switch (epi) {
         case EPI_SCORE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
-        case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
-        default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
     }
     return 0;
 }
