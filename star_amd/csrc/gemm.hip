@@ -12,12 +12,16 @@
 //   EPI_DH      G = ds[m]*w2[n]*(H>0) -> G, G^T (bf16) + column partials for dw2/db1   (backward 1)
 //   EPI_SLAB    fp32 split-K slab store                                      (dW1 = G^T X)
 //   EPI_ROWS    bf16 store with row scatter                                  (dX = G W1)
-// Tile 256x256x32, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
-// registers).  The large tile is what the kernel is built around: at 128x128 the L2 -> LDS operand traffic per
-// FLOP, not the MFMA rate, bounded it.  Operands are staged with global_load_lds (16 B/lane, LDS image
-// lane-linear) into a 4-stage ring (128 KiB) with ONE raw s_barrier per K tile and counted vmcnt, so two tiles of
-// loads stay in flight across every barrier; the XOR swizzle that makes the ds_read_b128 fragment reads
-// conflict-free is applied to the per-lane SOURCE address and to the read address (same involution).
+// Tile 256x256x64, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
+// registers).  Operands are staged with global_load_lds (16 B/lane, LDS image lane-linear) into two LDS buffers
+// of four 16-KiB half-tiles each (128 KiB).  A K tile is consumed in four phases, one accumulator quadrant
+// (64x32 per wave, 16 MFMAs) per phase; every phase reads the register sub-tile it needs, issues the LDS-DMA of
+// ONE half-tile seven half-tiles ahead, and is fenced by raw s_barriers.  The two waves that share a SIMD
+// (wave w and w+4, i.e. the two wave rows) run one barrier apart, so one of them is always in its MFMA block
+// while the other issues its ds_reads and DMA pieces (an LDS-DMA piece costs its wave 100+ issue cycles).
+// vmcnt is counted and waited once per K tile (three half-tiles stay in flight across it).  The XOR swizzle that
+// makes the ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address and to the read
+// address (same involution).
 // Workgroup -> tile mapping is XCD-aware: the column tiles of one row panel run on one XCD, so the
 // A panel is fetched into one L2 instead of eight.
 // Algorithmic work: forward 2*N_f*d*(d+1) FLOP; bytes: X 2*d*N_f + W1 2*d*d read, scores 4*N_f written.
@@ -26,18 +30,18 @@
 
 namespace star {
 
-constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;                 // 8 waves: 2 (M) x 4 (N), each 128 x 64
 constexpr int NWAVE = GEMM_THREADS / 64;
 constexpr int TM = 8, TN = 4;                     // 16x16 accumulator tiles per wave
-constexpr int ROW_BYTES = BK * 2;                 // 64-byte LDS rows
-constexpr int A_TILE_BYTES = BM * ROW_BYTES;      // 16 KiB
-constexpr int B_TILE_BYTES = BN * ROW_BYTES;      // 16 KiB
-constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
-constexpr int NSTAGE = 4;                         // ring of K tiles: two tiles of loads stay in flight
-constexpr int GEMM_LDS = NSTAGE * STAGE_BYTES;    // 128 KiB -> one workgroup (2 waves/SIMD) per CU
-constexpr int A_PIECES = BM / 16 / NWAVE;         // 1-KiB global_load_lds pieces (16 rows) per wave per K tile: 2
-constexpr int B_PIECES = BN / 16 / NWAVE;         // 2
+constexpr int ROW_BYTES = BK * 2;                 // 128-byte LDS rows (8 chunks of 16 B)
+constexpr int HALF_BYTES = 128 * ROW_BYTES;       // half-tile: 128 operand rows x 64 k = 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;         // B-half0 | A-half0 | B-half1 | A-half1
+constexpr int GEMM_LDS = 2 * BUF_BYTES;           // 128 KiB -> one workgroup (2 waves/SIMD) per CU
+// half-tile kinds in staging (= consumption) order.  A-half h holds, for both wave rows, the 64 rows of
+// accumulator quadrant row h (tile rows wr*128 + h*64 ..); B-half h the 32 columns wc*64 + h*32 .. of all four
+// wave columns.
+enum { H_B0 = 0, H_A0 = 1, H_B1 = 2, H_A1 = 3 };
 // epilogue staging (EPI_DH, EPI_ROWS): every wave parks its 128 x 64 bf16 output tile TRANSPOSED in LDS
 // ([64 n][128 m], pitch 272 B) so that global stores are 16 B per lane along whichever axis the consumer wants
 constexpr int EP_PITCH = 128 * 2 + 16;
@@ -79,12 +83,12 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// LDS image of an operand tile: [rows][4 chunks of 16 B]; chunk c of row r is stored at position
-// c ^ swz(r), swz(r) = (-(r >> 2)) & 3.  With this involution the 16 lanes that one ds_read_b128 cycle serves
-// (rows 0-3,12-15 of k-chunk q together with rows 4-11 of k-chunk q+1) fall on 16 distinct 16-B slots of the
-// 256-B bank row.  global_load_lds writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE
-// address when staging and to the address when reading (the same involution on both sides).
-__device__ __forceinline__ int swz4(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+// LDS image of a half-tile: [128 rows][8 chunks of 16 B]; chunk c of row r is stored at position c ^ swz8(r),
+// swz8(r) = (r >> 1) & 7.  With this involution the 16 lanes that one ds_read_b128 cycle serves (rows 0-3,12-15
+// of k-chunk q together with rows 4-11 of k-chunk q+1) fall on 16 distinct 16-B slots of the 256-B bank row.
+// global_load_lds writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE address when staging
+// and to the address when reading (the same involution on both sides).
+__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
 
 // rows of the wave's staged [n][m] tile -> GT[n][m] (16 B per lane, 256 B contiguous per row)
 __device__ __forceinline__ void ep_store_nrows(const uint8_t* W, __bf16* __restrict__ dstT, int64_t ld, int n_base,
@@ -136,27 +140,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     const int kc1 = min(p.kchunks, kc0 + cps);
     const int nk = max(0, kc1 - kc0);
 
-    // ---- per-lane staging sources.  Piece j covers tile rows j*16 .. +16; lane l -> row (l>>2), position (l&3).
-    const __bf16* asrc[A_PIECES];
-    const __bf16* bsrc[B_PIECES];
+    // ---- per-lane staging sources: wave w stages pieces 2w, 2w+1 (8 rows x 128 B each) of every half-tile;
+    // lane l -> half-tile row piece*8 + (l >> 3), LDS position l & 7, source chunk (l & 7) ^ swz8(row).
+    const __bf16* src[4][2];
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) {
-        const int row = (wid * A_PIECES + i) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int am = m0 + row;
-        if (am >= p.M) am = p.M - 1;
-        int64_t arow = am;
-        if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
-        asrc[i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
-    }
+    for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
-    for (int i = 0; i < B_PIECES; ++i) {
-        const int row = (wid * B_PIECES + i) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ swz4(row);
-        int bn = n0 + row;
-        if (bn >= p.N) bn = p.N - 1;
-        bsrc[i] = p.B + (int64_t)bn * p.ldb + (int64_t)kc0 * BK + chunk * 8;
-    }
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (wid * 2 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz8(hr);
+            const int hsel = kind >> 1;
+            if (kind & 1) {   // A operand
+                int am = m0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
+                if (am >= p.M) am = p.M - 1;
+                int64_t arow = am;
+                if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
+                src[kind][i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
+            } else {          // B operand
+                int bn = n0 + (hr >> 5) * 64 + hsel * 32 + (hr & 31);
+                if (bn >= p.N) bn = p.N - 1;
+                src[kind][i] = p.B + (int64_t)bn * p.ldb + (int64_t)kc0 * BK + chunk * 8;
+            }
+        }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -164,80 +169,117 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int buf, int kt) {
-        uint8_t* base = lds + buf * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) glds16(asrc[i] + (int64_t)kt * BK, base + (wid * A_PIECES + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            glds16(bsrc[i] + (int64_t)kt * BK, base + A_TILE_BYTES + (wid * B_PIECES + i) * 1024);
-    };
-
-    // fragment read: lane (frow = l&15, fq = l>>4) takes k-chunk fq of tile row (16*t + frow)
-    const int frow = lane & 15;
-    const int fq = lane >> 4;
-    const int foff = frow * ROW_BYTES + ((fq ^ swz4(frow)) << 4);    // swz4(16*t + frow) == swz4(frow)
-
-    // ---- 4-stage ring, ONE raw barrier per K tile, counted vmcnt (a __syncthreads() would drain the loads with
-    // vmcnt(0)).  Fragment reads are software-pipelined one tile ahead: in iteration kt the wave first issues the
-    // ds_reads of tile kt+1 into the other register set and then runs the 32 MFMAs of tile kt, so the LDS read
-    // burst of all 8 waves overlaps MFMA work instead of preceding it.
-    //   iteration kt: wait(tile kt+1 landed) -> barrier -> issue loads of tile kt+3 (its slot held tile kt-1,
-    //   whose fragments every wave consumed before this barrier) -> read frags kt+1 -> MFMA kt.
-    bf16x8 afA[TM], bfA[TN], afB[TM], bfB[TN];
-    auto read_frags = [&](int buf, bf16x8 (&af)[TM], bf16x8 (&bf)[TN]) {
-        const uint8_t* At = lds + buf * STAGE_BYTES + wr * (128 * ROW_BYTES) + foff;
-        const uint8_t* Bt = lds + buf * STAGE_BYTES + A_TILE_BYTES + wc * (64 * ROW_BYTES) + foff;
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bf[t] = *(const bf16x8*)(Bt + t * 16 * ROW_BYTES);
-#pragma unroll
-        for (int t = 0; t < TM; ++t) af[t] = *(const bf16x8*)(At + t * 16 * ROW_BYTES);
-    };
-    auto mma = [&](const bf16x8 (&af)[TM], const bf16x8 (&bf)[TN]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // one pipeline step: frags of tile kt are in (afc, bfc); fetch tile kt+1 into (afn, bfn)
-    auto step = [&](int kt, const bf16x8 (&afc)[TM], const bf16x8 (&bfc)[TN], bf16x8 (&afn)[TM], bf16x8 (&bfn)[TN]) {
-        // the current fragments were requested a whole MFMA block ago: retire them here (cheap), so that the
-        // compiler does not put an lgkmcnt(0) between the NEXT tile's ds_reads and this tile's MFMAs
-        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) only
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // tile kt+2 may still be in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // the two waves of a SIMD (wid and wid + 4, i.e. wr = 0 / 1) issue their LDS-DMA pieces at opposite
-            // ends of the step: a piece costs its wave 100+ issue cycles, during which the other wave's MFMAs run
-            if (wr == 0 && kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
-            read_frags((kt + 1) & (NSTAGE - 1), afn, bfn);
-        }
-        mma(afc, bfc);
-        if (wr == 1 && kt + 3 < nk) stage((kt + 3) & (NSTAGE - 1), kt + 3);
-    };
     // EPI_DH: the dscores of this tile's 256 rows are fetched by one thread per row while the main loop runs
     float my_ds = 0.f;
     if constexpr (EPI == EPI_DH) {
         if (tid < BM && m0 + tid < p.a_rows_n) my_ds = p.ds[p.a_rows[m0 + tid]];
     }
-    if (nk > 0) stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 2) stage(2, 2);
+
+#define STAR_STAGE(KIND, TILE)                                                                              \
+    do {                                                                                                    \
+        uint8_t* dst_ = lds + ((TILE) & 1) * BUF_BYTES + (KIND) * HALF_BYTES + wid * 2048;                  \
+        glds16(src[KIND][0] + (int64_t)(TILE) * BK, dst_);                                                  \
+        glds16(src[KIND][1] + (int64_t)(TILE) * BK, dst_ + 1024);                                           \
+    } while (0)
+
+    // fragment reads: lane (frow = l & 15, fq = l >> 4) takes k-chunk 4*ks + fq of half-tile row (base + frow);
+    // swz8(base + frow) == swz8(frow) because every base is a multiple of 16
+    const int frow = lane & 15, fq = lane >> 4;
+    const int choff0 = ((fq ^ swz8(frow)) << 4), choff1 = (((4 + fq) ^ swz8(frow)) << 4);
+    const int a_off = (wr * 64 + frow) * ROW_BYTES;
+    const int b_off = (wc * 32 + frow) * ROW_BYTES;
+    bf16x8 af[4][2], bfr[2][2][2];      // A quadrant rows (reloaded per row half), B both column halves
+    auto read_a = [&](int buf, int mh) {
+        const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + a_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff0);
+            af[i][1] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff1);
+        }
+    };
+    auto read_b0 = [&](int buf) {
+        const uint8_t* base = lds + buf * BUF_BYTES + H_B0 * HALF_BYTES + b_off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bfr[0][j][0] = *(const bf16x8*)(base + j * 16 * ROW_BYTES + choff0);
+            bfr[0][j][1] = *(const bf16x8*)(base + j * 16 * ROW_BYTES + choff1);
+        }
+    };
+    auto read_b1 = [&](int buf) {
+        const uint8_t* base = lds + buf * BUF_BYTES + H_B1 * HALF_BYTES + b_off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bfr[1][j][0] = *(const bf16x8*)(base + j * 16 * ROW_BYTES + choff0);
+            bfr[1][j][1] = *(const bf16x8*)(base + j * 16 * ROW_BYTES + choff1);
+        }
+    };
+#define STAR_MMA(MH, NH)                                                                                     \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                    acc[4 * (MH) + i][2 * (NH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(               \
+                        af[i][ks], bfr[NH][j][ks], acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0);                \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+
+    // ---- prologue: all of tile 0 and three half-tiles of tile 1 (seven half-tiles ahead, as in the loop)
     if (nk > 0) {
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, afA, bfA);
+        STAR_STAGE(H_B0, 0);
+        STAR_STAGE(H_A0, 0);
+        STAR_STAGE(H_B1, 0);
+        STAR_STAGE(H_A1, 0);
+        if (nk > 1) {
+            STAR_STAGE(H_B0, 1);
+            STAR_STAGE(H_A0, 1);
+            STAR_STAGE(H_B1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, afA, bfA, afB, bfB);
-        if (kt + 1 < nk) step(kt + 1, afB, bfB, afA, bfA);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // phase 1: quadrant (0,0).  The four B reads go first so that lgkmcnt(8) retires them before the barrier:
+        // their half-tile slot is re-staged in the next phase.
+        read_b0(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(buf, 0);
+        if (t + 1 < nk) STAR_STAGE(H_A1, t + 1);
+        __builtin_amdgcn_s_waitcnt(0xC87F);         // lgkmcnt(8)
+        STAR_MMA(0, 0);
+        // phase 2: quadrant (0,1)
+        read_b1(buf);
+        if (t + 2 < nk) STAR_STAGE(H_B0, t + 2);
+        STAR_MMA(0, 1);
+        // phase 3: quadrant (1,1)
+        read_a(buf, 1);
+        if (t + 2 < nk) STAR_STAGE(H_A0, t + 2);
+        STAR_MMA(1, 1);
+        // phase 4: quadrant (1,0); retire everything up to the end of tile t+1 (three half-tiles stay in flight)
+        if (t + 2 < nk) {
+            STAR_STAGE(H_B1, t + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        STAR_MMA(1, 0);
     }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the second wave row's last barrier
+    __builtin_amdgcn_sched_barrier(0);
+#undef STAR_STAGE
+#undef STAR_MMA
     __syncthreads();  // LDS is reused by the epilogues below
 
     // C layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + j
