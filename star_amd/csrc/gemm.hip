@@ -38,6 +38,7 @@ constexpr int ROW_BYTES = BK * 2;                 // 128-byte LDS rows (8 chunks
 constexpr int HALF_BYTES = 128 * ROW_BYTES;       // half-tile: 128 operand rows x 64 k = 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;         // B-half0 | A-half0 | B-half1 | A-half1
 constexpr int GEMM_LDS = 2 * BUF_BYTES;           // 128 KiB -> one workgroup (2 waves/SIMD) per CU
+constexpr int SCORE_LDS = GEMM_LDS + 4096;        // + row-reduction scratch that outlives the ring (persistent mode)
 // half-tile kinds in staging (= consumption) order.  A-half h holds, for both wave rows, the 64 rows of
 // accumulator quadrant row h (tile rows wr*128 + h*64 ..); B-half h the 32 columns wc*64 + h*32 .. of all four
 // wave columns.
@@ -126,13 +127,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 
     // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD whole
     // (row panel, K split) pairs so that all column tiles that share an A slab hit the same L2.
+    // EPI_SCORE runs PERSISTENT: a workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple
+    // of 8, so it stays on its XCD) and the operand stream of the next tile is staged behind the last K tiles of the
+    // current one, so only the first tile of a workgroup pays the pipeline prologue.
+    constexpr bool PERSIST = (EPI == EPI_SCORE);
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int panel = (local / nbn) * 8 + xcd;
-    const int n_tile = local % nbn;
-    if (panel >= nbm * p.splits) return;
-    const int m_tile = panel % nbm, split = panel / nbm;
+    auto map_tile = [&](int vb, int& mt, int& nt, int& sp) -> bool {
+        const int xcd = vb & 7, local = vb >> 3;
+        const int panel = (local / nbn) * 8 + xcd;
+        nt = local % nbn;
+        mt = panel % nbm;
+        sp = panel / nbm;
+        return panel < nbm * p.splits;
+    };
+    int vb = blockIdx.x;
+    int m_tile, n_tile, split;
+    if (!map_tile(vb, m_tile, n_tile, split)) return;
     int m0 = m_tile * BM, n0 = n_tile * BN;
 
     const int cps = (p.kchunks + p.splits - 1) / p.splits;
@@ -142,32 +152,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 
     // ---- per-lane staging sources: wave w stages pieces 2w, 2w+1 (8 rows x 128 B each) of every half-tile;
     // lane l -> half-tile row piece*8 + (l >> 3), LDS position l & 7, source chunk (l & 7) ^ swz8(row).
-    const __bf16* src[4][2];
+    auto make_src = [&](const __bf16* (&out)[4][2], int mm0, int nn0) {
 #pragma unroll
-    for (int kind = 0; kind < 4; ++kind)
+        for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int hr = (wid * 2 + i) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ swz8(hr);
-            const int hsel = kind >> 1;
-            if (kind & 1) {   // A operand
-                int am = m0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
-                if (am >= p.M) am = p.M - 1;
-                int64_t arow = am;
-                if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
-                src[kind][i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
-            } else {          // B operand
-                int bn = n0 + (hr >> 5) * 64 + hsel * 32 + (hr & 31);
-                if (bn >= p.N) bn = p.N - 1;
-                src[kind][i] = p.B + (int64_t)bn * p.ldb + (int64_t)kc0 * BK + chunk * 8;
+            for (int i = 0; i < 2; ++i) {
+                const int hr = (wid * 2 + i) * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ swz8(hr);
+                const int hsel = kind >> 1;
+                if (kind & 1) {   // A operand
+                    int am = mm0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
+                    if (am >= p.M) am = p.M - 1;
+                    int64_t arow = am;
+                    if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
+                    out[kind][i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
+                } else {          // B operand
+                    int bn = nn0 + (hr >> 5) * 64 + hsel * 32 + (hr & 31);
+                    if (bn >= p.N) bn = p.N - 1;
+                    out[kind][i] = p.B + (int64_t)bn * p.ldb + (int64_t)kc0 * BK + chunk * 8;
+                }
             }
-        }
+    };
+    const __bf16* src[4][2];
+    const __bf16* nsrc[4][2];
+    make_src(src, m0, n0);
 
     f32x4 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // EPI_DH: the dscores of this tile's 256 rows are fetched by one thread per row while the main loop runs
     float my_ds = 0.f;
@@ -175,11 +185,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         if (tid < BM && m0 + tid < p.a_rows_n) my_ds = p.ds[p.a_rows[m0 + tid]];
     }
 
-#define STAR_STAGE(KIND, TILE)                                                                              \
-    do {                                                                                                    \
-        uint8_t* dst_ = lds + ((TILE) & 1) * BUF_BYTES + (KIND) * HALF_BYTES + wid * 2048;                  \
-        glds16(src[KIND][0] + (int64_t)(TILE) * BK, dst_);                                                  \
-        glds16(src[KIND][1] + (int64_t)(TILE) * BK, dst_ + 1024);                                           \
+    // stage half-tile KIND of K tile TT of the current output tile; K tiles past the end belong to the next
+    // output tile of this workgroup (persistent mode).  UB = number of K tiles consumed so far: buffer parity.
+#define STAR_STAGE(KIND, TT)                                                                                 \
+    do {                                                                                                     \
+        uint8_t* dst_ = lds + ((ubase + (TT)) & 1) * BUF_BYTES + (KIND) * HALF_BYTES + wid * 2048;           \
+        if ((TT) < nk) {                                                                                     \
+            glds16(src[KIND][0] + (int64_t)(TT) * BK, dst_);                                                 \
+            glds16(src[KIND][1] + (int64_t)(TT) * BK, dst_ + 1024);                                          \
+        } else if (has_next) {                                                                               \
+            glds16(nsrc[KIND][0] + (int64_t)((TT) - nk) * BK, dst_);                                         \
+            glds16(nsrc[KIND][1] + (int64_t)((TT) - nk) * BK, dst_ + 1024);                                  \
+        }                                                                                                    \
     } while (0)
 
     // fragment reads: lane (frow = l & 15, fq = l >> 4) takes k-chunk 4*ks + fq of half-tile row (base + frow);
@@ -230,64 +247,75 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     } while (0)
 
     // ---- prologue: all of tile 0 and three half-tiles of tile 1 (seven half-tiles ahead, as in the loop)
-    if (nk > 0) {
-        STAR_STAGE(H_B0, 0);
-        STAR_STAGE(H_A0, 0);
-        STAR_STAGE(H_B1, 0);
-        STAR_STAGE(H_A1, 0);
-        if (nk > 1) {
-            STAR_STAGE(H_B0, 1);
-            STAR_STAGE(H_A0, 1);
-            STAR_STAGE(H_B1, 1);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    int ubase = 0;
+    bool has_next = false;
+    STAR_STAGE(H_B0, 0);
+    STAR_STAGE(H_A0, 0);
+    STAR_STAGE(H_B1, 0);
+    STAR_STAGE(H_A1, 0);
+    if (nk > 1) {
+        STAR_STAGE(H_B0, 1);
+        STAR_STAGE(H_A0, 1);
+        STAR_STAGE(H_B1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+
+  for (;;) {      // output tiles of this workgroup (one iteration unless PERSIST)
+    int nm_tile = 0, nn_tile = 0, nsplit = 0;
+    if constexpr (PERSIST) {
+        has_next = (nk >= 2) && map_tile(vb + (int)gridDim.x, nm_tile, nn_tile, nsplit);
+        if (has_next) make_src(nsrc, nm_tile * BM, nn_tile * BN);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier behind the first
     __builtin_amdgcn_sched_barrier(0);
 
     for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
+        const int buf = (ubase + t) & 1;
         // phase 1: quadrant (0,0).  The four B reads go first so that lgkmcnt(8) retires them before the barrier:
         // their half-tile slot is re-staged in the next phase.
         read_b0(buf);
         __builtin_amdgcn_sched_barrier(0);
         read_a(buf, 0);
-        if (t + 1 < nk) STAR_STAGE(H_A1, t + 1);
+        STAR_STAGE(H_A1, t + 1);
         __builtin_amdgcn_s_waitcnt(0xC87F);         // lgkmcnt(8)
         STAR_MMA(0, 0);
         // phase 2: quadrant (0,1)
         read_b1(buf);
-        if (t + 2 < nk) STAR_STAGE(H_B0, t + 2);
+        STAR_STAGE(H_B0, t + 2);
         STAR_MMA(0, 1);
         // phase 3: quadrant (1,1)
         read_a(buf, 1);
-        if (t + 2 < nk) STAR_STAGE(H_A0, t + 2);
+        STAR_STAGE(H_A0, t + 2);
         STAR_MMA(1, 1);
-        // phase 4: quadrant (1,0); retire everything up to the end of tile t+1 (three half-tiles stay in flight)
-        if (t + 2 < nk) {
-            STAR_STAGE(H_B1, t + 2);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // phase 4: quadrant (1,0); retire everything up to the end of K tile t+1 (three half-tiles stay in flight)
+        STAR_STAGE(H_B1, t + 2);
+        if (t + 2 < nk || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAR_MMA(1, 0);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the second wave row's last barrier
     __builtin_amdgcn_sched_barrier(0);
 #undef STAR_STAGE
 #undef STAR_MMA
-    __syncthreads();  // LDS is reused by the epilogues below
+    if constexpr (!PERSIST) __syncthreads();  // LDS is reused by the epilogues below (no DMA in flight any more)
 
     // C layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + j
     const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
     const int wrow0 = wr * 128, wcol0 = wc * 64;      // this wave's corner inside the tile
-    float* red = (float*)lds;
 
     if constexpr (EPI == EPI_SCORE) {
+        // persistent mode: the next tile's operands are landing in the ring right now, so the row reduction has
+        // its own LDS behind it and uses raw barriers (a __syncthreads() would drain the DMA queue)
+        float* red = (float*)(lds + GEMM_LDS);
         float bb[TN], ww[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -310,12 +338,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                 if (ccol == 0) red[(wrow0 + tm * 16 + crow4 + j) * 4 + wc] = s;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's partial sums are in LDS
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         static_assert(BM <= GEMM_THREADS, "one thread per tile row");
         if (tid < BM) {
-            const float* rr = red + tid * 4;
+            const f32x4 rr = *(const f32x4*)(red + tid * 4);
             p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
         }
+        // (the next write to `red` is a whole K loop of barriers away)
     } else if constexpr (EPI == EPI_DH) {
         uint8_t* W = lds + wid * EP_WAVE_BYTES;
         float* red2 = (float*)(lds + EP_RED_OFF);
@@ -434,6 +465,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             }
         }
     }
+
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (!has_next) break;
+        vb += (int)gridDim.x;
+        m_tile = nm_tile;
+        n_tile = nn_tile;
+        m0 = m_tile * BM;
+        n0 = n_tile * BN;
+#pragma unroll
+        for (int kind = 0; kind < 4; ++kind) {
+            src[kind][0] = nsrc[kind][0];
+            src[kind][1] = nsrc[kind][1];
+        }
+        ubase += nk;
+    }
+  }
 }
 
 // scores[m] = b2 + sum over column tiles of partial[t][m]   (fixed order -> reproducible)
@@ -528,20 +577,28 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
 
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
+    int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
     static bool attr_done[64] = {};
+    static int cus[64] = {};
     int dev = 0;
     hipGetDevice(&dev);
     dev &= 63;
     if (!attr_done[dev]) {
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
         hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_DH>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
         hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus[dev] = n / 8 * 8;
         attr_done[dev] = true;
     }
     switch (epi) {
-        case EPI_SCORE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
+        case EPI_SCORE:
+            // persistent: one workgroup per CU (a multiple of 8 keeps every workgroup on its XCD) walks the tiles
+            if (grid > cus[dev]) grid = cus[dev];
+            hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
+            break;
         case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
         default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
