@@ -86,6 +86,21 @@ def cpu_baseline(args, seconds):
                       f"{el:.1f} s"}
 
 
+def pmc_traffic(N, d):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
+    as the gfx950 note prescribes + WRITE_SIZE; profiles/r01_v13_pmc_scorer_fwd.json).  PMC passes cannot run
+    inside this process, so the figure is only reported for the exact workload it was collected on; else None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v13_pmc_scorer_fwd.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("algorithmic_bytes_per_launch") == N * d * 2 + d * d * 2 + N * 4:
+            return round(float(doc["traffic_bytes_per_launch"]))
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     from star_amd import dist as sd
@@ -184,7 +199,7 @@ def main():
         ach = flops / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_SCORE> (+ scorer_finish_kernel)", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": None, "avg_us": round(avg_ms * 1e3, 2), "flop_per_launch": flops}
+                    "traffic": pmc_traffic(N, d), "avg_us": round(avg_ms * 1e3, 2), "flop_per_launch": flops}
 
     if args.breakdown and rank == 0:
         breakdown(scorer, inp, rate, dev)
