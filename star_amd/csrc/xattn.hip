@@ -479,6 +479,278 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
     }
 }
 
+// ---- LDS-DMA ring variant of the dQ kernel (HD = 64 or 128).  One workgroup = 8 waves x 16 queries.  K / V /
+// bias tiles of 64 keys are streamed by global_load_lds (lane-linear LDS image, XOR swizzle on the per-lane
+// SOURCE address and on the read address) into a 4-stage ring: ONE raw barrier per tile, counted vmcnt, two
+// tiles in flight across every barrier, so HBM stays busy from the first cycle to the last.  16x16x32 MFMAs,
+// query on the MFMA column: S^T = K Q^T and dP^T = V dO^T (A rows from LDS, B = Q / dO fragments in registers),
+// dS^T is packed in-lane into the B operand of dQ^T = K^T dS^T (A by ds_read_b64_tr_b16 of the same K tile).
+template <int HD>
+struct Ring {
+    static constexpr int KT2 = 64, NST = 4, WAVES = 8;
+    static constexpr int ROWB = HD * 2;
+    static constexpr int TILE = KT2 * ROWB;                 // one operand tile
+    static constexpr int STAGE = 2 * TILE + KT2 * 4;        // K | V | bias
+    static constexpr int BYTES = NST * STAGE;
+    static constexpr int PIECES = TILE / 1024 / WAVES;      // 1-KiB DMA pieces per wave per operand tile
+    static constexpr int RPP = 1024 / ROWB;                 // rows per piece
+    static_assert(PIECES >= 1, "tile too small for 8 waves");
+    __device__ static __forceinline__ int swz(int r) {
+        if constexpr (HD == 128) return (r & 7) << 1;
+        else return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 2) & 1);
+    }
+};
+
+__device__ __forceinline__ void xa_glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void xa_glds4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform)
+__device__ __forceinline__ void xa_wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Transposed LDS read as inline asm.  The compiler has no memory operand for the ds_read_tr builtin, so next to an
+// LDS-DMA in flight it drains vmcnt(0) before every one of them (which serialises the ring); an asm read is not
+// tracked at all: the caller waits with xa_wait_lds() before the first use of the results.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <int OFF2>
+__device__ __forceinline__ bf16x8 lds_tr8_async(uint32_t addr) {
+    bf16x4 a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(OFF2));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void xa_wait_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Register loads that the compiler does not track (so that it does not drain the LDS-DMA queue with vmcnt(0) at
+// their first use): the caller counts them and waits with xa_wait_vm() + sched_barrier before using the values.
+// (macros, not functions: the asm writes the destination variable itself, so no register copy of a value that
+// has not arrived yet can be scheduled between the load and the wait)
+#define XA_GLOAD16_ASYNC(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define XA_GLOAD4_ASYNC(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+
+// issue the DMA of K / V / bias tile `tile` (keys tile*64 ..) into ring slot tile % NST
+template <int HD>
+__device__ __forceinline__ void ring_stage(uint8_t* smem, const __bf16* Kb, int64_t k_sr, const __bf16* Vb, int64_t v_sr,
+                                           const float* bias_row, int bias_len, int Kn, int tile, int wid, int lane) {
+    using R = Ring<HD>;
+    uint8_t* st = smem + (tile % R::NST) * R::STAGE;
+    const int key0 = tile * R::KT2;
+#pragma unroll
+    for (int i = 0; i < R::PIECES; ++i) {
+        const int piece = wid * R::PIECES + i;
+        const int row = piece * R::RPP + lane / (R::ROWB / 16);
+        const int pos = lane % (R::ROWB / 16);
+        const int chunk = pos ^ R::swz(row & 15);
+        const int key = min(key0 + row, Kn - 1);
+        xa_glds16(Kb + (int64_t)key * k_sr + chunk * 8, st + piece * 1024);
+        xa_glds16(Vb + (int64_t)key * v_sr + chunk * 8, st + R::TILE + piece * 1024);
+    }
+    if (wid == 0) {
+        // bias[key] for the 64 keys of the tile (keys past bias_len read a valid address and are zeroed at use)
+        const int key = min(key0 + lane, max(bias_len, 1) - 1);
+        xa_glds4(bias_row + key, st + 2 * R::TILE);
+    }
+}
+
+template <int HD, bool HAS_BIAS>
+__global__ __launch_bounds__(512) void xattn_bwd_dq_ring_kernel(
+    const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
+    const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
+    float* __restrict__ delta, const float* __restrict__ bias, const float* __restrict__ zero_bias,
+    const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dQ) {
+    using R = Ring<HD>;
+    constexpr int ROWB = R::ROWB, KT2 = R::KT2;
+    constexpr int KS = HD / 32;       // k-steps of a 16x16x32 MFMA over the head dim
+    constexpr int NT = HD / 16;       // 16-wide head-dim tiles of dQ^T
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wid * 16;      // first query of this wave
+    const int q = q0 + r16;
+    const int qc = min(q, s.L - 1);
+
+    const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+    const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+    const float* bias_row = HAS_BIAS ? bias + (int64_t)b * s.bias_len : zero_bias;
+    const int bias_len = HAS_BIAS ? s.bias_len : 0;
+
+    int kend = s.Kn;
+    if (key_len) kend = min(kend, key_len[b]);
+    // keys the workgroup / this wave have to visit
+    int kloop_wg = kend, kloop = kend;
+    if (s.ilk_diag >= 0) {
+        kloop_wg = min(kend, min((int)blockIdx.x * 128 + 128, s.L) + s.ilk_diag);
+        kloop = min(kend, min(q0 + 16, s.L) + s.ilk_diag);
+    }
+    if (q0 >= s.L) kloop = 0;
+    const int ntiles = (kloop_wg + KT2 - 1) / KT2;
+    const int ppt = 2 * R::PIECES + (wid == 0 ? 1 : 0);      // DMA operations of this wave per tile
+
+    // tile 0 first, then the register operands (untracked asm loads), then tiles 1 and 2
+    if (ntiles > 0) ring_stage<HD>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, 0, wid, lane);
+
+    const __bf16* qrow = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)qc * s.q_sr + g * 8;
+    const __bf16* orow = O + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh + (int64_t)qc * s.o_sr + g * 8;
+    const __bf16* grow = dO + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh + (int64_t)qc * s.o_sr + g * 8;
+    bf16x8 qf[KS], gf[KS], of[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        XA_GLOAD16_ASYNC(qf[ks], qrow + ks * 32);
+        XA_GLOAD16_ASYNC(gf[ks], grow + ks * 32);
+        XA_GLOAD16_ASYNC(of[ks], orow + ks * 32);
+    }
+    float my_lse2;
+    XA_GLOAD4_ASYNC(my_lse2, lse + ((int64_t)b * s.h + h) * s.L + qc);
+    // tiles 1 and 2 follow at once, so HBM stays busy; then wait for everything older than them
+    if (ntiles > 1) ring_stage<HD>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, 1, wid, lane);
+    if (ntiles > 2) ring_stage<HD>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, 2, wid, lane);
+    xa_wait_vm(ppt * min(2, max(ntiles - 1, 0)));
+    __builtin_amdgcn_sched_barrier(0);
+    float my_delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) my_delta += (float)gf[ks][j] * (float)of[ks][j];
+    my_delta += __shfl_xor(my_delta, 16, 64);
+    my_delta += __shfl_xor(my_delta, 32, 64);
+    if (g == 0 && q < s.L) delta[((int64_t)b * s.h + h) * s.L + q] = my_delta;
+    my_lse2 *= LOG2E;
+    const float scale2 = s.scale * LOG2E;
+
+    // per-lane visibility limit: key visible  <=>  key < klim
+    int klim = kend;
+    if (s.ilk_diag >= 0) klim = min(klim, q + s.ilk_diag + 1);
+    if (q >= s.L) klim = 0;
+    // every lane of the wave sees all keys below klim_wave (0: the wave holds rows past L -> always masked path)
+    int klim_wave = kend;
+    if (s.ilk_diag >= 0) klim_wave = min(klim_wave, q0 + s.ilk_diag + 1);
+    if (q0 + 16 > s.L) klim_wave = 0;
+
+    f32x4 dq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int sw_row = R::swz(r16);
+    const int tr_row = 4 * g + (r16 >> 2);
+    const int sw_tr = R::swz(tr_row);
+
+#pragma unroll 1
+    for (int tile = 0; tile < ntiles; ++tile) {
+        // tile `tile` has landed once at most the DMAs of the (up to two) younger tiles are outstanding
+        xa_wait_vm(ppt * min(2, ntiles - 1 - tile));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // slot (tile+3) % 4 held tile-1, which every wave finished reading before the barrier above
+        if (tile + 3 < ntiles)
+            ring_stage<HD>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, tile + 3, wid, lane);
+        const uint8_t* k_lds = smem + (tile % R::NST) * R::STAGE;
+        const uint8_t* v_lds = k_lds + R::TILE;
+        const float* b_lds = (const float*)(k_lds + 2 * R::TILE);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb0 = tile * KT2 + sub * 32;
+            if (kb0 >= kloop) break;                  // wave-uniform
+            bf16x8 ka[2][KS], va[2][KS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rowoff = (sub * 32 + 16 * t + r16) * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = rowoff + (((4 * ks + g) ^ sw_row) << 4);
+                    ka[t][ks] = lds_row8(k_lds + off);
+                    va[t][ks] = lds_row8(v_lds + off);
+                }
+            }
+            f32x4 bb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bb[t] = *(const f32x4*)(b_lds + sub * 32 + 16 * t + 4 * g);
+            f32x4 sacc[2], pacc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                pacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t][ks], qf[ks], sacc[t], 0, 0, 0);
+                    pacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[t][ks], gf[ks], pacc[t], 0, 0, 0);
+                }
+            // transposed K fragments: in flight during the softmax arithmetic
+            const uint32_t trp = lds_addr(k_lds + (sub * 32 + tr_row) * ROWB + 8 * (lane & 1));
+            bf16x8 kt[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                kt[nt] = lds_tr8_async<16 * ROWB>(trp + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4));
+            // dS^T = P^T * (dP^T - delta), P^T = exp2(S^T*scale2 + bias2 - lse2); masks only where a step needs them
+            bf16x8 df;
+            const bool plain = (kb0 + 32 <= klim_wave) && (!HAS_BIAS || kb0 + 32 <= bias_len);    // wave-uniform
+            if (plain) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c = HAS_BIAS ? __builtin_fmaf(bb[t][j], LOG2E, -my_lse2) : -my_lse2;
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][j], scale2, c));
+                        df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = kb0 + 16 * t + 4 * g + j;
+                        const float bj = (HAS_BIAS && key < bias_len) ? bb[t][j] * LOG2E : 0.f;
+                        float p = __builtin_amdgcn_exp2f(sacc[t][j] * scale2 + bj - my_lse2);
+                        p = (key < klim) ? p : 0.f;
+                        df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
+                    }
+            }
+            xa_wait_lds();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[nt], df, dq[nt], 0, 0, 0);
+        }
+    }
+
+    if (q < s.L) {
+        __bf16* drow = dQ + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)q * s.q_sr + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4 o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = (__bf16)(dq[nt][j] * s.scale);
+            *(bf16x4*)(drow + nt * 16) = o4;
+        }
+    }
+}
+
 // ============================================================================================ dK, dV, dbias
 constexpr int KB = 128;   // keys per workgroup (32 per wave)
 constexpr int QS = 32;    // query rows per slice
@@ -999,9 +1271,35 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
         set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_dq);
         return STAR_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq, st,
-                       (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o, (const __bf16*)do_, lse,
-                       delta, bias, key_len, *s, (__bf16*)dq);
+    static const char* dq_force = getenv("STAR_XA_DQ");        // "gen" = always the general variant (A/B runs)
+    bool dq_done = false;
+    if constexpr (HD == 64 || HD == 128) {
+        if (!dq_force) {
+            const int smem_s = Ring<HD>::BYTES;
+            const bool hb = bias && s->bias_len > 0;
+            const void* kfn = hb ? (const void*)xattn_bwd_dq_ring_kernel<HD, true>
+                                 : (const void*)xattn_bwd_dq_ring_kernel<HD, false>;
+            hipError_t e4 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_s);
+            if (e4 != hipSuccess) {
+                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
+                return STAR_ERR_LAUNCH;
+            }
+            // without a bias the DMA of the bias slot reads `lse` (any valid floats: never used)
+            if (hb)
+                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, true>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(512),
+                                   smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
+                                   (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len, *s, (__bf16*)dq);
+            else
+                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, false>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(512),
+                                   smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
+                                   (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len, *s, (__bf16*)dq);
+            dq_done = true;
+        }
+    }
+    if (!dq_done)
+        hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq,
+                           st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
+                           (const __bf16*)do_, lse, delta, bias, key_len, *s, (__bf16*)dq);
     static const char* dkv_force = getenv("STAR_XA_DKV");      // "gen" = always the general variant (A/B runs)
     if constexpr (HD == 64 || HD == 128) {
         if (s->L <= DkvSmall<HD>::QROWS && !dkv_force) {
