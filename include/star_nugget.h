@@ -49,12 +49,14 @@ const char* star_last_error(void);
  * Outputs (any may be NULL except idx_out):
  *   idx_out [B,K] int64 ascending kept indices then ascending pad-slot indices,
  *   mask_out [B,K] uint8 (j < k_b), scores_gather [B,K] fp32 = scores[b, idx_out],
- *   type_table [B,T] int64 0/1, positions [B,K] int64 (= idx_out with pad slots set to -1).
+ *   type_table [B,T] int64 0/1, positions [B,K] int64 (= idx_out with pad slots set to -1),
+ *   flat_rows [B*K] int32 = b*T + idx_out[b,j]: the frame ids of the selected slots in the flattened [B*T]
+ *   frame axis, i.e. the `rows` list star_scorer_bwd takes (needs B*T < 2^31).
  * Tie rule: equal keys rank by lower frame index first. */
 int star_topk_select(const float* scores, const uint8_t* attn_mask, const int32_t* lengths,
                      const int32_t* n_nugget, float ratio, int B, int T, int K,
                      int64_t* idx_out, uint8_t* mask_out, float* scores_gather,
-                     int64_t* type_table, int64_t* positions, void* stream);
+                     int64_t* type_table, int64_t* positions, int32_t* flat_rows, void* stream);
 
 /* Stand-alone add_nugget_type_embedding (w2v_asr.py:316-323; w2v_simul.py:273-280) for callers that already
  * hold indices and mask: type_table [B,T] int64 = 1 at kept frames, positions [B,K] int64 = idx with masked

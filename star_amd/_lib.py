@@ -37,7 +37,7 @@ _SZ = C.c_size_t
 SIGNATURES = {
     "star_version": (_I, []),
     "star_last_error": (C.c_char_p, []),
-    "star_topk_select": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "star_topk_select": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "star_nugget_type_table": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "star_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I64, _P]),
     "star_gather_rows_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -95,7 +95,7 @@ __device__ void radix_select(const uint32_t* keys, int T, uint32_t k, uint32_t* 
 __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
     const float* __restrict__ scores, const uint8_t* __restrict__ attn_mask,
     const int32_t* __restrict__ lengths, const int32_t* __restrict__ n_nugget, float ratio, int T,
-    int K, int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out,
+    int K, int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out, int32_t* __restrict__ flat_rows,
     float* __restrict__ scores_gather, int64_t* __restrict__ type_table,
     int64_t* __restrict__ positions) {
     extern __shared__ uint32_t smem[];
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
         uint32_t slot = (c == 1) ? p1++ : (uint32_t)kb + p2++;
         if (slot < (uint32_t)K) {
             irow[slot] = i;
+            if (flat_rows) flat_rows[(size_t)b * K + slot] = b * T + i;
             if (scores_gather) scores_gather[(size_t)b * K + slot] = srow[i];
             if (positions) positions[(size_t)b * K + slot] = (c == 1) ? (int64_t)i : (int64_t)-1;
         }
@@ -223,9 +224,10 @@ extern "C" int star_nugget_type_table(const int64_t* idx, const uint8_t* nugget_
 extern "C" int star_topk_select(const float* scores, const uint8_t* attn_mask, const int32_t* lengths,
                                 const int32_t* n_nugget, float ratio, int B, int T, int K,
                                 int64_t* idx_out, uint8_t* mask_out, float* scores_gather,
-                                int64_t* type_table, int64_t* positions, void* stream) {
+                                int64_t* type_table, int64_t* positions, int32_t* flat_rows, void* stream) {
     using namespace star;
     STAR_REQUIRE(scores && idx_out, "star_topk_select: scores and idx_out must be non-null");
+    STAR_REQUIRE(!flat_rows || (int64_t)B * T < (1ll << 31), "star_topk_select: B*T too large for int32 flat rows");
     STAR_REQUIRE((attn_mask != nullptr) != (lengths != nullptr),
                  "star_topk_select: give exactly one of attn_mask / lengths");
     STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && K <= T, "star_topk_select: need B>=1, 1<=K<=T (B=%d T=%d K=%d)", B, T, K);
@@ -240,7 +242,7 @@ extern "C" int star_topk_select(const float* scores, const uint8_t* attn_mask, c
         }
     }
     hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, (hipStream_t)stream, scores,
-                       attn_mask, lengths, n_nugget, ratio, T, K, idx_out, mask_out, scores_gather,
+                       attn_mask, lengths, n_nugget, ratio, T, K, idx_out, mask_out, flat_rows, scores_gather,
                        type_table, positions);
     STAR_LAUNCH_CHECK("star_topk_select");
     return STAR_OK;

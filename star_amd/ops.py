@@ -55,44 +55,53 @@ class _TopkSelect(torch.autograd.Function):
     Differentiable only through scores_gather (w2v_asr.py:243)."""
 
     @staticmethod
-    def forward(ctx, scores, mask_u8, lengths_i32, n_nugget_i32, ratio, K, want_table):
+    def forward(ctx, scores, mask_u8, lengths_i32, n_nugget_i32, ratio, K, want_table, want_rows):
         B, T = scores.shape
         dev = scores.device
+        ctx.set_materialize_grads(False)      # no zero tensors for the integer / mask outputs
         s = scores.detach().to(torch.float32).contiguous()
         idx = torch.empty((B, K), dtype=torch.int64, device=dev)
         nmask = torch.empty((B, K), dtype=torch.uint8, device=dev)
         sg = torch.empty((B, K), dtype=torch.float32, device=dev)
         table = torch.empty((B, T), dtype=torch.int64, device=dev) if want_table else None
         pos = torch.empty((B, K), dtype=torch.int64, device=dev) if want_table else None
+        rows = torch.empty((B * K,), dtype=torch.int32, device=dev) if want_rows else None
         check(lib().star_topk_select(ptr(s), ptr(mask_u8), ptr(lengths_i32), ptr(n_nugget_i32), float(ratio),
-                                     B, T, K, ptr(idx), ptr(nmask), ptr(sg), ptr(table), ptr(pos), stream_ptr()),
-              "star_topk_select")
+                                     B, T, K, ptr(idx), ptr(nmask), ptr(sg), ptr(table), ptr(pos), ptr(rows),
+                                     stream_ptr()), "star_topk_select")
         ctx.save_for_backward(idx)
         ctx.T = T
         ctx.in_dtype = scores.dtype
         nmask = nmask.view(torch.bool)
         ctx.mark_non_differentiable(idx, nmask)
+        outs = [nmask, idx, sg.to(scores.dtype)]
         if want_table:
             ctx.mark_non_differentiable(table, pos)
-            return nmask, idx, sg.to(scores.dtype), table, pos
-        return nmask, idx, sg.to(scores.dtype)
+            outs += [table, pos]
+        if want_rows:
+            ctx.mark_non_differentiable(rows)
+            outs.append(rows)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_mask, g_idx, g_sg, *rest):
+        if g_sg is None:
+            return None, None, None, None, None, None, None, None
         (idx,) = ctx.saved_tensors
         B, K = idx.shape
         g = g_sg.to(torch.float32).contiguous()
         ds = torch.empty((B, ctx.T), dtype=torch.float32, device=g.device)
         check(lib().star_gather_rows_bwd(ptr(g), ptr(idx), ptr(ds), B, ctx.T, K, 1, DT_F32, stream_ptr()),
               "star_gather_rows_bwd")
-        return ds.to(ctx.in_dtype), None, None, None, None, None, None
+        return ds.to(ctx.in_dtype), None, None, None, None, None, None, None
 
 
 def topk_select(scores, attn_mask=None, lengths=None, rate: Optional[float] = None, n_nugget=None,
-                K: Optional[int] = None, want_table: bool = True):
+                K: Optional[int] = None, want_table: bool = True, want_rows: bool = False):
     """Top-k anchor selection.  `K` (= max_b k_b) may be passed to avoid a device->host sync; when it is
     None it is derived from the lengths exactly like the reference (w2v_asr.py:227: `n_nugget.max()`),
-    which costs one small readback."""
+    which costs one small readback.  want_rows appends the flat int32 frame ids b*T + idx (the active-row list of the
+    scorer backward) to the returned tuple."""
     _need_cuda(scores, attn_mask, lengths, n_nugget)
     mask_u8, lengths_i32 = _mask_or_lengths(attn_mask, lengths)
     nn_i32 = None if n_nugget is None else n_nugget.to(torch.int32).contiguous()
@@ -105,7 +114,7 @@ def topk_select(scores, attn_mask=None, lengths=None, rate: Optional[float] = No
         else:
             n_tok = mask_u8.sum(dim=1) if mask_u8 is not None else lengths_i32
             K = int(nugget_counts_host(n_tok.cpu().numpy(), rate).max())
-    return _TopkSelect.apply(scores, mask_u8, lengths_i32, nn_i32, ratio, int(K), want_table)
+    return _TopkSelect.apply(scores, mask_u8, lengths_i32, nn_i32, ratio, int(K), want_table, bool(want_rows))
 
 
 def type_table(nugget_indices, nugget_mask, T: int):
@@ -128,6 +137,7 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, src, idx):
+        ctx.set_materialize_grads(False)
         squeeze = src.dim() == 2
         s3 = src.unsqueeze(-1) if squeeze else src
         s3 = s3.contiguous()
@@ -144,6 +154,8 @@ class _GatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         (idx,) = ctx.saved_tensors
         B, T, d = ctx.shape
         K = idx.shape[1]
@@ -209,6 +221,7 @@ class _CifQuantity(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scores, mask_u8, lengths_i32, target_i32, threshold):
+        ctx.set_materialize_grads(False)
         B, T = scores.shape
         s = scores.detach().to(torch.float32).contiguous()
         alphas = torch.empty_like(s)
@@ -225,6 +238,8 @@ class _CifQuantity(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_alphas, g_loss):
+        if g_loss is None:
+            return None, None, None, None, None
         alphas, diff = ctx.saved_tensors
         B, T = alphas.shape
         gl = g_loss.to(torch.float32).reshape(1).contiguous()
@@ -306,6 +321,7 @@ class _Scorer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, hint):
+        ctx.set_materialize_grads(False)
         d = x.shape[-1]
         xb = x.detach()
         if xb.dtype != torch.bfloat16:
@@ -337,6 +353,8 @@ class _Scorer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None, None
         xb, w1b, w1t, b1f, w2f = ctx.saved_tensors
         N, d = xb.shape
         dev = xb.device
@@ -392,6 +410,7 @@ class _XAttn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs):
+        ctx.set_materialize_grads(False)
         in_dtype = q.dtype
         qb, kb, vb = (t.detach() if t.dtype == torch.bfloat16 else t.detach().to(torch.bfloat16) for t in (q, k, v))
         B, h, L, hd = qb.shape
@@ -418,6 +437,8 @@ class _XAttn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, g_probs):
+        if g is None:
+            return None, None, None, None, None, None, None, None
         qb, kb, vb, o, lse, bias_f, kl = ctx.saved_tensors
         ilk_diag, scale, bias_len = ctx.cfg
         B, h, L, hd = qb.shape

@@ -98,9 +98,8 @@ def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward
     B, T, d = inp.x.shape
     key_len, K = inp.key_len_dev(rate)
     scores = scorer(inp.x).squeeze(-1).float()
-    nmask, idx, sg, table, pos = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K)
-    # frames that can receive a score gradient: the B*K selected slots (pad slots get exact zeros)
-    rows = (idx + torch.arange(B, device=idx.device).unsqueeze(1) * T).to(torch.int32).reshape(-1)
+    # rows: frames that can receive a score gradient = the B*K selected slots (pad slots get exact zeros)
+    nmask, idx, sg, table, pos, rows = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K, want_rows=True)
     scorer.set_active_rows(rows)
     mem = ops.gather_rows(inp.s, idx)
     outs, loss = _attend(inp, mem, sg, key_len, -1, with_loss)

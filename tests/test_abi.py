@@ -39,7 +39,7 @@ def test_argument_errors_do_not_need_a_gpu():
     """Shape validation happens on the host before any launch and reports through star_last_error()."""
     from star_amd import _lib
     L = _lib.lib()
-    rc = L.star_topk_select(None, None, None, None, 0.25, 1, 8, 2, None, None, None, None, None, None)
+    rc = L.star_topk_select(None, None, None, None, 0.25, 1, 8, 2, None, None, None, None, None, None, None)
     assert rc == -1 and b"star_topk_select" in L.star_last_error()
     rc = L.star_scorer_fwd(None, None, None, None, None, 10, 100, None, None, 0, None)
     assert rc == -1

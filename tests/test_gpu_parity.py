@@ -72,7 +72,10 @@ def test_select_random_vs_oracle(ops, B, T, rate):
     lengths = rng.integers(1, T + 1, size=B)
     lengths[0] = T
     mask = lmask(lengths, T)
-    nmask, idx, sg, table, pos = ops.topk_select(dev(scores), lengths=dev(lengths, torch.int32), rate=rate)
+    nmask, idx, sg, table, pos, rows = ops.topk_select(dev(scores), lengths=dev(lengths, torch.int32), rate=rate,
+                                                       want_rows=True)
+    flat = idx.cpu().numpy() + np.arange(B)[:, None] * T
+    assert rows.dtype == torch.int32 and np.array_equal(rows.cpu().numpy(), flat.reshape(-1))
     o_mask, o_idx, o_sg = orc.topk_select(scores, mask, rate)
     o_table, o_pos = orc.type_table(T, o_idx, o_mask)
     np.testing.assert_array_equal(nmask.cpu().numpy(), o_mask)
