@@ -495,28 +495,43 @@ __global__ void scorer_finish_kernel(const float* __restrict__ partial, int64_t 
     scores[m] = s;
 }
 
-// XT[i][r] = X[rows[r]][i] for r < R, 0 for R <= r < Rpad   (bf16, 64x64 tiles through LDS)
-__global__ __launch_bounds__(256) void gather_transpose_kernel(const __bf16* __restrict__ X, int64_t ldx,
-                                                               const int32_t* __restrict__ rows, int R, int Rpad,
-                                                               int d, __bf16* __restrict__ XT) {
-    __shared__ __bf16 tile[64][66];
-    const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int rr = ty; rr < 64; rr += 4) {
-        const int r = r0 + rr;
-        __bf16 v = (__bf16)0.0f;
-        if (r < R) v = X[(int64_t)rows[r] * ldx + i0 + tx];
-        tile[rr][tx] = v;
-    }
-    __syncthreads();
-    for (int ii = ty; ii < 64; ii += 4) {
-        const int r = r0 + tx;
-        if (r < Rpad) XT[(int64_t)(i0 + ii) * Rpad + r] = tile[tx][ii];
+// 64x64 bf16 tile in LDS, pitch 144 B: rows are written 16 B at a time and read back column-wise (8 rows of one
+// column -> one 16-B vector), so both the global reads and the global writes of a transpose are 16 B per lane
+constexpr int TP_PITCH = 144;
+__device__ __forceinline__ void tp_write_out(const uint8_t* tile, __bf16* __restrict__ dstT, int64_t ld, int i0, int r0) {
+    // thread t: output rows ii = t/8 (+32), 8 consecutive r starting at (t%8)*8
+    const int t = threadIdx.x, rb = (t & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int ii = (t >> 3) + pass * 32;
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *(const __bf16*)(tile + (rb + k) * TP_PITCH + ii * 2);
+        *(bf16x8*)(dstT + (int64_t)(i0 + ii) * ld + r0 + rb) = v;
     }
 }
 
+// XT[i][r] = X[rows[r]][i] for r < R, 0 for R <= r < Rpad   (bf16; d % 64 == 0, Rpad % 64 == 0)
+__global__ __launch_bounds__(256) void gather_transpose_kernel(const __bf16* __restrict__ X, int64_t ldx,
+                                                               const int32_t* __restrict__ rows, int R, int Rpad,
+                                                               int d, __bf16* __restrict__ XT) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TP_PITCH];
+    const int r0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int t = threadIdx.x, c = t & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rr = (t >> 3) + pass * 32;
+        const int r = r0 + rr;
+        u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+        if (r < R) v = *(const u32x4*)(X + (int64_t)rows[r] * ldx + i0 + c * 8);
+        *(u32x4*)(tile + rr * TP_PITCH + c * 16) = v;
+    }
+    __syncthreads();
+    tp_write_out(tile, XT, Rpad, i0, r0);
+}
+
 // dst[r][c] = bf16(src[r][c]);  dst_t[c][r] = bf16(src[r][c])
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
+__global__ __launch_bounds__(256) void cast_transpose_generic_kernel(const float* __restrict__ src, int rows, int cols,
                                                              __bf16* __restrict__ dst, __bf16* __restrict__ dst_t) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -533,6 +548,30 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
             const int c = c0 + cc, r = r0 + tx;
             if (r < rows && c < cols) dst_t[(int64_t)c * rows + r] = (__bf16)tile[tx][cc];
         }
+}
+
+// same for rows % 64 == 0 and cols % 64 == 0: 16-byte accesses on every side
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
+                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TP_PITCH];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x, c = t & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rr = (t >> 3) + pass * 32;
+        const float* sp = src + (int64_t)(r0 + rr) * cols + c0 + c * 8;
+        const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (__bf16)a[k];
+            v[4 + k] = (__bf16)b[k];
+        }
+        if (dst) *(bf16x8*)(dst + (int64_t)(r0 + rr) * cols + c0 + c * 8) = v;
+        *(bf16x8*)(tile + rr * TP_PITCH + c * 16) = v;
+    }
+    __syncthreads();
+    if (dst_t) tp_write_out(tile, dst_t, rows, c0, r0);
 }
 
 // dw1 = sum of split-K slabs; db1/dw2 = sum of column partials; db2 = sum of dscores over rows[]
@@ -754,8 +793,14 @@ extern "C" int star_cast_transpose_bf16(const float* src, int rows, int cols, vo
     using namespace star;
     STAR_REQUIRE(src && (dst || dst_t), "star_cast_transpose_bf16: null pointer");
     STAR_REQUIRE(rows >= 1 && cols >= 1, "star_cast_transpose_bf16: bad shape %d x %d", rows, cols);
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(cols, 64), cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
-                       src, rows, cols, (__bf16*)dst, (__bf16*)dst_t);
+    const bool fast = rows % 64 == 0 && cols % 64 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) &&
+                      ((uintptr_t)dst_t % 16 == 0);
+    if (fast)
+        hipLaunchKernelGGL(cast_transpose_kernel, dim3(cols / 64, rows / 64), dim3(256), 0, (hipStream_t)stream, src,
+                           rows, cols, (__bf16*)dst, (__bf16*)dst_t);
+    else
+        hipLaunchKernelGGL(cast_transpose_generic_kernel, dim3(cdiv(cols, 64), cdiv(rows, 64)), dim3(256), 0,
+                           (hipStream_t)stream, src, rows, cols, (__bf16*)dst, (__bf16*)dst_t);
     STAR_LAUNCH_CHECK("star_cast_transpose_bf16");
     return STAR_OK;
 }

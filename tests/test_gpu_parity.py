@@ -225,6 +225,19 @@ def _scorer_case(B, T, d, seed):
     return x, w1, b1, w2, b2
 
 
+@pytest.mark.parametrize("rows,cols", [(128, 192), (1024, 1024), (70, 33)])
+def test_cast_transpose(ops, rows, cols):
+    """fp32 -> bf16 copy + transposed copy (weight preparation of the scorer): bit-exact vs torch rounding."""
+    from star_amd import _lib
+    src = torch.randn(rows, cols, generator=torch.Generator().manual_seed(rows + cols)).to(DEV)
+    dst = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    dst_t = torch.empty(cols, rows, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.lib().star_cast_transpose_bf16(_lib.ptr(src), rows, cols, _lib.ptr(dst), _lib.ptr(dst_t),
+                                                   _lib.stream_ptr()), "star_cast_transpose_bf16")
+    ref = src.to(torch.bfloat16)
+    assert torch.equal(dst, ref) and torch.equal(dst_t, ref.t().contiguous())
+
+
 @pytest.mark.parametrize("B,T,d", [(4, 250, 768), (2, 301, 1024), (1, 37, 128)])
 def test_scorer_forward_backward(ops, B, T, d):
     x, w1, b1, w2, b2 = _scorer_case(B, T, d, B + T + d)
