@@ -174,8 +174,147 @@ def gen_scorer():
          dw2=model[2].weight.grad, db2=model[2].bias.grad)
 
 
+# ------------------------------------------------------------------ (6) end-to-end call-site fixtures
+def _compat_patches():
+    """transformers >= 5 dropped helpers that the 4.34 pin provided (API drift): restore their
+    4.34 semantics on the reference classes (head split/merge = view + permute, no head mask)."""
+    A = my_transformer.MyGPT2Attention
+    if not hasattr(A, "_split_heads"):
+        A._split_heads = lambda self, t, nh, hd: t.view(t.size()[:-1] + (nh, hd)).permute(0, 2, 1, 3)
+    if not hasattr(A, "_merge_heads"):
+        A._merge_heads = lambda self, t, nh, hd: t.permute(0, 2, 1, 3).contiguous().view(t.size()[:-3] + (t.size(-2), nh * hd))
+    M = my_transformer.MyGPT2Model
+    M.get_head_mask = lambda self, head_mask, n_layer, *a, **k: [None] * n_layer
+
+
+class _FakeEncoder(torch.nn.Module):
+    def __init__(self, x, mask):
+        super().__init__()
+        self.x, self.mask = x, mask
+
+    def forward(self, audio_seq, attention_mask=None):
+        return SimpleNamespace(last_hidden_state=self.x), self.mask
+
+
+class _FakeSemantic(torch.nn.Module):
+    def __init__(self, d, g):
+        super().__init__()
+        self.type_embed = torch.nn.Embedding(2, d)
+        self.proj = torch.nn.Linear(d, d)
+        with torch.no_grad():
+            self.type_embed.weight.copy_(torch.randn(2, d, generator=g) * 0.1)
+            self.proj.weight.copy_(torch.randn(d, d, generator=g) / d ** 0.5)
+            self.proj.bias.zero_()
+
+    def forward(self, inputs_embeds=None, attention_mask=None):
+        return SimpleNamespace(last_hidden_state=torch.tanh(self.proj(inputs_embeds)))
+
+
+def e2e_w1(seed, d):
+    rng = np.random.default_rng(seed)
+    return ((rng.random((d, d), dtype=np.float32) * 2 - 1) / np.float32(d ** 0.5)).astype(np.float32)
+
+
+def _run_e2e(kind, use_ilk, seed):
+    from transformers import GPT2Config
+    _compat_patches()
+    g = torch.Generator().manual_seed(seed)
+    d, B, T, L, V, nl = 512, 2, 40, 12, 37, 2
+    lengths = [40, 29]
+    tlen = [12, 9]
+    mask = len_mask(lengths, T)
+    x = torch.randn(B, T, d, generator=g)
+    x = (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True)
+    cls = w2v_asr.W2VASRModel if kind == "asr" else w2v_simul.W2VSimulModel
+    m = cls.__new__(cls)
+    torch.nn.Module.__init__(m)
+    m.disable_nuggets = False
+    m.nugget_compress_rate = 4
+    m.nugget_model = torch.nn.Sequential(torch.nn.Linear(d, d), torch.nn.ReLU(inplace=True), torch.nn.Linear(d, 1))
+    with torch.no_grad():
+        for prm in m.nugget_model.parameters():
+            prm.copy_((torch.rand(prm.shape, generator=g) * 2 - 1) / d ** 0.5)
+        # W1 (1 MB) is not stored: it is regenerated from a numpy PCG64 stream, with a probe to verify it
+        m.nugget_model[0].weight.copy_(torch.from_numpy(e2e_w1(seed, d)))
+        if kind == "simul":
+            m.nugget_model[2].bias.fill_(-1.0)      # sigmoid(scores) ~ 0.27: sum of alphas in the range of L
+    m.encoder = _FakeEncoder(x, mask)
+    m.semantic_encoder = _FakeSemantic(d, g)
+    cfg = GPT2Config(n_embd=d, vocab_size=V, num_labels=V, n_positions=64, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                     n_layer=nl, n_head=8, add_cross_attention=True, attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0)
+    torch.manual_seed(seed)
+    if kind == "asr":
+        m.lm_decoder = my_transformer.MyGPT2ForLM(cfg)
+    else:
+        m.limit_cross_attention = use_ilk
+        m.lm_decoder = my_transformer.MyGPT2ForLM(cfg, limit_cross_attn=use_ilk)
+    for mod in m.lm_decoder.modules():          # 4.34 registered the causal buffer on self-attention modules
+        if isinstance(mod, my_transformer.MyGPT2Attention) and not getattr(mod, "is_cross_attention", False) \
+                and not hasattr(mod, "bias"):
+            mod.register_buffer("bias", torch.tril(torch.ones(64, 64, dtype=torch.bool)).view(1, 1, 64, 64), persistent=False)
+    m.train()
+
+    # record every cross-attention core call: inputs, output and (through hooks) their gradients
+    rec = []
+    orig_attn = my_transformer.MyGPT2Attention._attn
+
+    def spy(self, query, key, value, attention_mask=None, head_mask=None, scorer_logits=None, limit_cross_attn=False, **kw):
+        out = orig_attn(self, query, key, value, attention_mask, head_mask, scorer_logits=scorer_logits,
+                        limit_cross_attn=limit_cross_attn, **kw)
+        if getattr(self, "is_cross_attention", False):
+            e = {"q": query, "k": key, "v": value, "o": out[0], "mask": attention_mask, "ilk": bool(limit_cross_attn)}
+            for t in (query, key, value, out[0]):
+                t.retain_grad()
+            rec.append(e)
+        return out
+
+    my_transformer.MyGPT2Attention._attn = spy
+    spy_sel = {}
+    orig_sel = cls.apply_nugget_compression if kind == "asr" else None
+    try:
+        text = torch.randint(3, V, (B, L), generator=g)
+        lm_mask = len_mask(tlen, L)
+        labels = text.masked_fill(~lm_mask, -100)
+        # keep handles on the intermediate tensors of the model method
+        orig_nm_forward = m.nugget_model.forward
+        keep = {}
+
+        def nm_forward(inp):
+            out = orig_nm_forward(inp)
+            out.retain_grad()
+            keep["scores3"] = out
+            return out
+
+        m.nugget_model.forward = nm_forward
+        misc = {}
+        loss, misc = m.lm_nugget_training(None, mask, text, lm_mask.long(), labels, misc)
+        loss.backward()
+    finally:
+        my_transformer.MyGPT2Attention._attn = orig_attn
+    nm = m.nugget_model
+    scores = keep["scores3"].detach().squeeze(-1)
+    out = dict(x=x, lengths=np.array(lengths), target_lengths=np.array(tlen), rate=4, use_ilk=int(use_ilk),
+               w1_seed=seed, w1_probe=nm[0].weight.detach()[::97, ::89], b1=nm[0].bias, w2=nm[2].weight, b2=nm[2].bias,
+               scores=scores, dscores=keep["scores3"].grad.squeeze(-1),
+               dw1_rows64=nm[0].weight.grad[:64], db1=nm[0].bias.grad, dw2=nm[2].weight.grad, db2=nm[2].bias.grad,
+               loss=loss.detach(), nugget_position=misc["nugget_indices"], n_layers=len(rec))
+    if "quantity_loss" in misc:
+        out["quantity_loss"] = np.float32(misc["quantity_loss"])
+    for i, e in enumerate(rec):
+        out[f"q{i}"], out[f"k{i}"], out[f"v{i}"], out[f"o{i}"] = e["q"], e["k"], e["v"], e["o"]
+        out[f"dq{i}"], out[f"dk{i}"], out[f"dv{i}"], out[f"do{i}"] = e["q"].grad, e["k"].grad, e["v"].grad, e["o"].grad
+        out[f"mask{i}"] = e["mask"]
+    save(f"e2e_{kind}" + ("_ilk" if use_ilk else ""), **out)
+
+
+def gen_e2e():
+    _run_e2e("asr", False, 101)
+    _run_e2e("simul", False, 102)
+    _run_e2e("simul", True, 103)
+
+
 if __name__ == "__main__":
-    gen_select()
-    gen_cif()
-    gen_xattn()
-    gen_scorer()
+    only = sys.argv[1:]
+    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e):
+        if not only or fn.__name__ in only:
+            fn()

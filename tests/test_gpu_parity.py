@@ -499,3 +499,81 @@ def test_nugget_step_simul_runs_and_matches_oracle_pieces(ops):
         assert torch.isfinite(out["loss"]).item()
         assert scorer[0].weight.grad is not None and torch.isfinite(scorer[0].weight.grad).all()
         assert inp.x.grad is None                      # the simul path detaches X (w2v_simul.py:410)
+
+
+# ------------------------------------------------------------------------------------------------ e2e call sites
+@pytest.mark.parametrize("name", ["e2e_asr", "e2e_simul", "e2e_simul_ilk"])
+def test_e2e_call_sites_gpu(ops, name):
+    """Whole-model run of the reference (fixtures from tests/golden/gen_golden.py): the
+    HIP path, chained over the recorded call-site tensors exactly like the reference chains its own ops, must give
+    the reference's selection (bit-exact, on the reference's scores), every cross-attention output and gradient,
+    the total scorer-logit gradient and the nugget_model parameter gradients (bf16-MFMA bars of section 2)."""
+    from star_amd.nugget import NuggetScorer
+    from tests.test_oracle_golden import e2e_w1
+    g = load(name)
+    simul = "quantity_loss" in g
+    B, T, d = g["x"].shape
+    w1 = e2e_w1(g)
+    scorer = NuggetScorer(d).to(DEV)
+    with torch.no_grad():
+        scorer[0].weight.copy_(dev(w1))
+        scorer[0].bias.copy_(dev(g["b1"]))
+        scorer[2].weight.copy_(dev(g["w2"]))
+        scorer[2].bias.copy_(dev(g["b2"]))
+    x = dev(g["x"], torch.bfloat16)
+    scores = scorer(x).squeeze(-1).float()
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), g["scores"], atol=2e-2, rtol=2e-2)
+    # selection on the reference's own scores: integer-exact
+    lengths = dev(g["lengths"], torch.int32)
+    tl = dev(g["target_lengths"], torch.int32)
+    ref_scores = dev(g["scores"])
+    if simul:
+        alphas, _ = ops.cif_quantity(ref_scores, tl, lengths=lengths)
+        resized = ops.cif_resize(alphas, tl)
+        idx, nmask, counts, _, _ = ops.cif_fire_scan(resized, lengths=lengths, cap=g["nugget_position"].shape[1])
+        key_len = counts
+    else:
+        nmask, idx, _, table, pos = ops.topk_select(ref_scores, lengths=lengths, rate=float(g["rate"]))
+        key_len = nmask.sum(1).to(torch.int32)
+    pos = torch.where(nmask.bool(), idx, torch.full_like(idx, -1))
+    np.testing.assert_array_equal(pos.cpu().numpy(), g["nugget_position"])
+    # differentiable chain on the HIP scores: gather -> nl x core -> sum <O, dO> (+ 0.01 quantity loss)
+    sg = ops.gather_rows(scores, pos if simul else idx)
+    total = 0.0
+    qkv = []
+    for l in range(int(g["n_layers"])):
+        q, k, v = (dev(g[f"{n}{l}"], torch.bfloat16).requires_grad_() for n in "qkv")
+        o, _ = ops.xattn(q, k, v, bias=sg, key_len=key_len, ilk_diag=2 if int(g["use_ilk"]) else -1)
+        ref_o = g[f"o{l}"]
+        np.testing.assert_allclose(o.detach().float().cpu().numpy(), ref_o, atol=2e-2 * np.abs(ref_o).max(), rtol=2e-2)
+        total = total + (o.float() * dev(g[f"do{l}"])).sum()
+        qkv.append((q, k, v))
+    if simul:
+        _, ql = ops.cif_quantity(scores, tl, lengths=lengths)
+        np.testing.assert_allclose(ql.item(), float(g["quantity_loss"]), rtol=2e-2)
+        total = total + 0.01 * ql
+    scores.retain_grad()
+    total.backward()
+
+    def close(got, ref, what, gate_flips=0.0):
+        """|got - ref| <= 2e-2 * (max|ref| + |ref|).  gate_flips: admitted fraction of outliers for dW1 / db1, whose
+        terms ds*w2*[h > 0] are gated by the sign of h: a pre-activation within bf16 rounding of 0 flips its gate when
+        X and W1 are rounded to bf16, which moves that element by one whole term (measured: < 1 % of the elements)."""
+        ref = np.asarray(ref)
+        got = got.detach().float().cpu().numpy().reshape(ref.shape)
+        bad = np.abs(got - ref) > 2e-2 * np.abs(ref).max() + 2e-2 * np.abs(ref)
+        assert bad.mean() <= gate_flips, f"{what}: {bad.sum()} of {bad.size} elements off"
+
+    for l, (q, k, v) in enumerate(qkv):
+        close(q.grad, g[f"dq{l}"], f"dq{l}")
+        close(k.grad, g[f"dk{l}"], f"dk{l}")
+        close(v.grad, g[f"dv{l}"], f"dv{l}")
+    close(scores.grad, g["dscores"], "dscores")
+    close(scorer[0].weight.grad[:64], g["dw1_rows64"], "dW1", gate_flips=0.02)
+    close(scorer[0].bias.grad, g["db1"], "db1", gate_flips=0.02)
+    close(scorer[2].weight.grad, g["dw2"], "dw2")
+    ref_db2 = np.asarray(g["db2"])
+    # db2 = sum of dscores, analytically 0 in the ASR path (softmax is shift invariant): the bf16 rounding errors of
+    # the individual terms do not cancel, so the bar is relative to sum |dscores| (measured 1.3e-3 of it)
+    np.testing.assert_allclose(scorer[2].bias.grad.cpu().numpy(), ref_db2, rtol=2e-2,
+                               atol=5e-3 * np.abs(g["dscores"]).sum())

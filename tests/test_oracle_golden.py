@@ -146,3 +146,74 @@ def test_gather_rows_negative_index():
     assert torch.equal(mem[0, 2], src[0, 4]) and torch.equal(mem[1, 1], src[1, 4])
     mem.sum().backward()
     assert src.grad[1, 4, 0] == 3 and src.grad[0, 1, 0] == 0
+
+
+# ------------------------------------------------------------------ (6) end-to-end call-site fixtures
+E2E = ["e2e_asr", "e2e_simul", "e2e_simul_ilk"]
+
+
+def e2e_w1(g):
+    """W1 of the e2e fixtures is regenerated from its numpy PCG64 seed (tests/golden/gen_golden.py: e2e_w1) and
+    verified against the stored probe."""
+    d = g["x"].shape[-1]
+    rng = np.random.default_rng(int(g["w1_seed"]))
+    w1 = ((rng.random((d, d), dtype=np.float32) * 2 - 1) / np.float32(d ** 0.5)).astype(np.float32)
+    np.testing.assert_array_equal(w1[::97, ::89], g["w1_probe"])
+    return w1
+
+
+def e2e_select(g, scores):
+    """The reference's nugget selection at its call site, restated with the oracle: returns
+    (mask [B,K] bool, idx [B,K] int64 (pads as the reference leaves them), extra dscores term or None)."""
+    B, T = scores.shape
+    mask = lmask(g["lengths"], T)
+    if "quantity_loss" not in g:
+        nmask, idx, _ = orc.topk_select(scores, mask, float(g["rate"]))
+        return mask, nmask, idx
+    s = torch.from_numpy(scores)
+    alphas, _ = orc.quantity_loss(s, torch.from_numpy(mask), torch.from_numpy(g["target_lengths"]))
+    resized = orc.resize(alphas, torch.from_numpy(g["target_lengths"]))
+    nmask, idx, _ = orc.fire_scan(resized.numpy(), mask, with_block_mask=False)
+    return mask, nmask, idx
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_e2e_call_sites(name):
+    """Whole-model run of the reference (tiny decoder, fake encoders): the oracle,
+    chained over the recorded call-site tensors, must reproduce the reference's selection, every cross-attention
+    output and gradient, the total scorer-logit gradient and the nugget_model parameter gradients."""
+    g = load(name)
+    w1 = e2e_w1(g)
+    x = torch.from_numpy(g["x"])
+    w = [torch.from_numpy(a).clone().requires_grad_() for a in (w1, g["b1"], g["w2"], g["b2"])]
+    scores = orc.scorer(x, *w)
+    np.testing.assert_allclose(scores.detach().numpy(), g["scores"], rtol=1e-5, atol=1e-6)
+    mask, nmask, idx = e2e_select(g, g["scores"])
+    pos = np.where(nmask, idx, -1)
+    np.testing.assert_array_equal(pos, g["nugget_position"])
+    # scorer logits handed to the decoder (differentiable gather; -1 addresses the last frame in the simul path)
+    gidx = torch.from_numpy(idx if "quantity_loss" not in g else pos)
+    sg = orc.gather_rows(scores, gidx)
+    total = 0.0
+    for l in range(int(g["n_layers"])):
+        q, k, v = (torch.from_numpy(g[f"{n}{l}"]).clone().requires_grad_() for n in "qkv")
+        key_mask = torch.from_numpy(g[f"mask{l}"][:, 0, 0, :] == 0)          # inverted additive mask: 0 = attend
+        np.testing.assert_array_equal(key_mask.numpy(), nmask)
+        o, _ = orc.xattn_core(q, k, v, key_mask, sg, limit_cross_attn=bool(g["use_ilk"]))
+        np.testing.assert_allclose(o.detach().numpy(), g[f"o{l}"], rtol=1e-4, atol=1e-5)
+        total = total + (o * torch.from_numpy(g[f"do{l}"])).sum()
+        gq, gk, gv = torch.autograd.grad((o * torch.from_numpy(g[f"do{l}"])).sum(), (q, k, v), retain_graph=True)
+        for got, ref in ((gq, g[f"dq{l}"]), (gk, g[f"dk{l}"]), (gv, g[f"dv{l}"])):
+            np.testing.assert_allclose(got.numpy(), ref, rtol=1e-3, atol=2e-7)
+    if "quantity_loss" in g:
+        _, ql = orc.quantity_loss(scores, torch.from_numpy(mask), torch.from_numpy(g["target_lengths"]))
+        np.testing.assert_allclose(ql.item(), float(g["quantity_loss"]), rtol=1e-5)
+        total = total + 0.01 * ql
+    scores.retain_grad()
+    total.backward()
+    np.testing.assert_allclose(scores.grad.numpy(), g["dscores"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(w[0].grad.numpy()[:64], g["dw1_rows64"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(w[1].grad.numpy(), g["db1"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(w[2].grad.numpy(), g["dw2"], rtol=1e-3, atol=1e-8)
+    # db2 = sum of dscores: analytically 0 in the ASR path (softmax is shift invariant), so bound it by the terms
+    np.testing.assert_allclose(w[3].grad.numpy(), g["db2"], rtol=1e-3, atol=1e-5 * np.abs(g["dscores"]).sum())
