@@ -140,14 +140,19 @@ int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float*
 /* Backward for the R rows listed in rows[] (frame ids into x; the frames whose dscore is non-zero):
  *   dscores [N] fp32 (full), rows [R] int32, w1t = transpose of w1 ([in,out] bf16) for dx.
  * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),
- *   dx [N,d] bf16 or NULL: rows listed in rows[] are written, all other rows must have been zeroed
- *   by the caller.
+ *   dx [N,d] bf16 or NULL: rows listed in rows[] are written; all other rows are zero-filled by the call
+ *   unless dx_zeroed != 0 says the caller has done so already.
+ * aux_stream (may be NULL): a second stream of the same device.  When given, the memory-bound helpers of the
+ *   call (dx zero-fill, X_sel^T, the split-K / column reductions) run on it beside the GEMMs; the call forks from
+ *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
+ *   `stream` captures both branches).  Calls with different stream pairs must not overlap on one device.
  * workspace: star_scorer_bwd_workspace(R,d) bytes. */
 size_t star_scorer_bwd_workspace(int64_t R, int d);
 int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1,
                     const float* w2, const float* dscores, const int32_t* rows, int64_t R,
                     int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int dx_zeroed, void* workspace, size_t workspace_bytes, void* stream,
+                    void* aux_stream);
 /* fp32 [rows,cols] -> bf16 copy and bf16 transpose (the per-step weight cast of W1). */
 int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream);
 

@@ -693,6 +693,32 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
     return STAR_OK;
 }
 
+namespace star {
+// Fork / join between the caller's stream and its auxiliary stream (both supplied by the caller).  The events are
+// created once per device and reused: an event only orders work recorded before the wait, so back-to-back calls
+// on the same pair of streams are safe; calls on different stream pairs must not run concurrently on one device.
+struct AuxEvents {
+    hipEvent_t fork[2], join[2];
+    bool ok;
+};
+static AuxEvents* aux_events() {
+    static AuxEvents ev[64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    AuxEvents* e = &ev[dev & 63];
+    if (!e->ok) {
+        bool good = true;
+        for (int i = 0; i < 2; ++i) {
+            good = good && hipEventCreateWithFlags(&e->fork[i], hipEventDisableTiming) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&e->join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        e->ok = good;
+        if (!good) return nullptr;
+    }
+    return e;
+}
+}  // namespace star
+
 extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
     using namespace star;
     if (R <= 0 || d <= 0) return 0;
@@ -704,8 +730,8 @@ extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
 
 extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1, const float* w2,
                                const float* dscores, const int32_t* rows, int64_t R, int64_t N, int d, float* dw1,
-                               float* db1, float* dw2, float* db2, void* dx, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               float* db1, float* dw2, float* db2, void* dx, int dx_zeroed, void* workspace,
+                               size_t workspace_bytes, void* stream, void* aux_stream) {
     using namespace star;
     STAR_REQUIRE(x && w1 && b1 && w2 && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
                  "star_scorer_bwd: null pointer");
@@ -728,6 +754,20 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     float* colpart = (float*)(ws + 3 * gbytes);
     float* slab = (float*)(ws + 3 * gbytes + align256(((size_t)2 * nbm * d + nbm) * 4));
 
+    // Two independent chains: the MFMA-bound GEMMs stay on `stream`; the memory-bound helpers (zero-fill of dx,
+    // X_sel^T, the slab / column reductions) run beside them on `aux_stream` when the caller provides one.
+    hipStream_t aux = aux_stream ? (hipStream_t)aux_stream : st;
+    AuxEvents* ev = (aux != st) ? aux_events() : nullptr;
+    if (aux != st && !ev) aux = st;                    // could not create events: run serially
+    if (aux != st) {
+        hipEventRecord(ev->fork[0], st);
+        hipStreamWaitEvent(aux, ev->fork[0], 0);
+    }
+    // aux: dx zero-fill (rows that are not listed) and X_sel^T
+    if (dx && !dx_zeroed) hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux);
+    hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
+                       (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
+    if (aux != st) hipEventRecord(ev->join[0], aux);
     // 1. recompute H for the listed rows, emit G = dH and G^T, column partials for dw2 / db1
     GemmParams p = {};
     p.A = (const __bf16*)x;
@@ -748,10 +788,8 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     p.ldgt = Rpad;
     p.colpart = colpart;
     launch_gemm(EPI_DH, p, st);
-    // 2. X_sel^T
-    hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, st,
-                       (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
-    // 3. dW1 = G^T . X_sel  (split-K slabs)
+    if (aux != st) hipStreamWaitEvent(st, ev->join[0], 0);
+    // 2. dW1 = G^T . X_sel  (split-K slabs)
     GemmParams q = {};
     q.A = GT;
     q.B = XT;
@@ -763,12 +801,17 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     q.splits = splits;
     q.slab = slab;
     launch_gemm(EPI_SLAB, q, st);
-    // 4. reductions
+    // 3. reductions (on aux, beside the dX GEMM)
+    if (aux != st) {
+        hipEventRecord(ev->fork[1], st);
+        hipStreamWaitEvent(aux, ev->fork[1], 0);
+    }
     const int64_t dd = (int64_t)d * d;
     const int nblk_dw1 = cdiv(dd, 1024);
-    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(nblk_dw1 + 2 * d / 64), dim3(256), 0, st, (const float*)slab,
+    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(nblk_dw1 + 2 * d / 64), dim3(256), 0, aux, (const float*)slab,
                        splits, dd, dw1, (const float*)colpart, nbm, d, dw2, db1, db2, nblk_dw1);
-    // 5. dX rows = G . W1
+    if (aux != st) hipEventRecord(ev->join[1], aux);
+    // 4. dX rows = G . W1
     if (dx) {
         GemmParams r = {};
         r.A = G;
@@ -785,6 +828,7 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
         r.out_rows_n = (int)R;
         launch_gemm(EPI_ROWS, r, st);
     }
+    if (aux != st) hipStreamWaitEvent(st, ev->join[1], 0);
     STAR_LAUNCH_CHECK("star_scorer_bwd");
     return STAR_OK;
 }

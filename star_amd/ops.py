@@ -316,6 +316,19 @@ class ActiveRows:
         self.rows = None
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(dev):
+    """Second stream handed to star_scorer_bwd for its memory-bound helpers (one per device and calling stream)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _AUX_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _AUX_STREAMS[key] = st
+    return st
+
+
 class _Scorer(torch.autograd.Function):
     """scores = w2 . relu(W1 x + b1) + b2 (w2v_asr.py:113-117,553); bf16 MFMA, fp32 accumulate/scores."""
 
@@ -365,16 +378,17 @@ class _Scorer(torch.autograd.Function):
         rows = rows.to(torch.int32).contiguous().view(-1)
         R = rows.numel()
         need_dx = ctx.needs_input_grad[0]
-        dx = torch.zeros((N, d), dtype=torch.bfloat16, device=dev) if need_dx else None
+        dx = torch.empty((N, d), dtype=torch.bfloat16, device=dev) if need_dx else None   # zero-filled by the call
         dw1 = torch.empty((d, d), dtype=torch.float32, device=dev)
         db1 = torch.empty((d,), dtype=torch.float32, device=dev)
         dw2 = torch.empty((d,), dtype=torch.float32, device=dev)
         db2 = torch.empty((1,), dtype=torch.float32, device=dev)
         wsb = lib().star_scorer_bwd_workspace(R, d)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        aux = _aux_stream(dev)
         check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1t), ptr(b1f), ptr(w2f), ptr(ds), ptr(rows), R, N, d,
-                                    ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), ptr(ws), wsb, stream_ptr()),
-              "star_scorer_bwd")
+                                    ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0, ptr(ws), wsb, stream_ptr(),
+                                    aux.cuda_stream), "star_scorer_bwd")
         t1, t2, t3, t4 = ctx.w_dtypes
         gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
         return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None)
