@@ -251,6 +251,8 @@ def breakdown(scorer, inp, rate, dev):
         torch.cuda.synchronize()
         print(f"[breakdown] {name:28s} {a.elapsed_time(b) / n * 1e3:9.1f} us", file=sys.stderr, flush=True)
 
+    print("[breakdown] eager launches: stage times include host launch overhead; per-kernel GPU times are in "
+          "profiles/*_kernel_stats.csv", file=sys.stderr, flush=True)
     key_len, K = inp.key_len_dev(rate)
     with torch.no_grad():
         scores = scorer(inp.x).squeeze(-1).float()

@@ -1214,6 +1214,17 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_probs_kernel(const __bf16* _
     }
 }
 
+// hipFuncSetAttribute costs tens of microseconds on the host: do it once per kernel and device
+static bool reserve_lds(const void* fn, int bytes, bool* done) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    dev &= 63;
+    if (done[dev]) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done[dev] = true;
+    return true;
+}
+
 static int check_shape(const star_xattn_shape* s, const char* who) {
     STAR_REQUIRE(s, "%s: null shape", who);
     STAR_REQUIRE(s->B >= 1 && s->h >= 1 && s->L >= 1 && s->Kn >= 1, "%s: bad shape B=%d h=%d L=%d Kn=%d", who, s->B,
@@ -1232,9 +1243,9 @@ template <int HD, int NG>
 static int launch_fwd_ng(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
                          const star_xattn_shape* s, void* o, float* lse, hipStream_t st) {
     const int smem = FwdLds<HD, NG>::BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)xattn_fwd_kernel<HD, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-        set_error("star_xattn_fwd: cannot reserve %d bytes of LDS: %s", smem, hipGetErrorString(e));
+    static bool done[64] = {};
+    if (!reserve_lds((const void*)xattn_fwd_kernel<HD, NG>, smem, done)) {
+        set_error("star_xattn_fwd: cannot reserve %d bytes of LDS", smem);
         return STAR_ERR_LAUNCH;
     }
     dim3 grid(cdiv(s->L, 128), s->h, s->B);
@@ -1265,12 +1276,6 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
                          const float* lse, const float* bias, const int32_t* key_len, const star_xattn_shape* s,
                          void* dq, void* dk, void* dv, float* delta, float* dbias_part, hipStream_t st) {
     const int smem_dq = DqLds<HD, NG>::BYTES;
-    hipError_t e1 = hipFuncSetAttribute((const void*)xattn_bwd_dq_kernel<HD, NG>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
-    if (e1 != hipSuccess) {
-        set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_dq);
-        return STAR_ERR_LAUNCH;
-    }
     static const char* dq_force = getenv("STAR_XA_DQ");        // "gen" = always the general variant (A/B runs)
     bool dq_done = false;
     if constexpr (HD == 64 || HD == 128) {
@@ -1279,8 +1284,8 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
             const bool hb = bias && s->bias_len > 0;
             const void* kfn = hb ? (const void*)xattn_bwd_dq_ring_kernel<HD, true>
                                  : (const void*)xattn_bwd_dq_ring_kernel<HD, false>;
-            hipError_t e4 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_s);
-            if (e4 != hipSuccess) {
+            static bool done_ring[2][64] = {};
+            if (!reserve_lds(kfn, smem_s, done_ring[hb ? 1 : 0])) {
                 set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
                 return STAR_ERR_LAUNCH;
             }
@@ -1296,17 +1301,22 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
             dq_done = true;
         }
     }
-    if (!dq_done)
+    if (!dq_done) {
+        static bool done_dq[64] = {};
+        if (!reserve_lds((const void*)xattn_bwd_dq_kernel<HD, NG>, smem_dq, done_dq)) {
+            set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_dq);
+            return STAR_ERR_LAUNCH;
+        }
         hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq,
                            st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
                            (const __bf16*)do_, lse, delta, bias, key_len, *s, (__bf16*)dq);
+    }
     static const char* dkv_force = getenv("STAR_XA_DKV");      // "gen" = always the general variant (A/B runs)
     if constexpr (HD == 64 || HD == 128) {
         if (s->L <= DkvSmall<HD>::QROWS && !dkv_force) {
             const int smem_s = DkvSmall<HD>::BYTES;
-            hipError_t e3 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_small_kernel<HD>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_s);
-            if (e3 != hipSuccess) {
+            static bool done_small[64] = {};
+            if (!reserve_lds((const void*)xattn_bwd_dkv_small_kernel<HD>, smem_s, done_small)) {
                 set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
                 return STAR_ERR_LAUNCH;
             }
@@ -1323,9 +1333,8 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
         }
     }
     const int smem_r = DkvRegLds<HD>::BYTES;
-    hipError_t e3 = hipFuncSetAttribute((const void*)xattn_bwd_dkv_reg_kernel<HD>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem_r);
-    if (e3 != hipSuccess) {
+    static bool done_reg[64] = {};
+    if (!reserve_lds((const void*)xattn_bwd_dkv_reg_kernel<HD>, smem_r, done_reg)) {
         set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_r);
         return STAR_ERR_LAUNCH;
     }

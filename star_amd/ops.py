@@ -385,10 +385,12 @@ class _Scorer(torch.autograd.Function):
         db2 = torch.empty((1,), dtype=torch.float32, device=dev)
         wsb = lib().star_scorer_bwd_workspace(R, d)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        aux = _aux_stream(dev)
+        # the fork/join costs four event operations on the host: worth it when the launches are replayed from a HIP
+        # graph (no host cost at replay), not for eager launches, which are host-bound already
+        aux = _aux_stream(dev) if torch.cuda.is_current_stream_capturing() else None
         check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1t), ptr(b1f), ptr(w2f), ptr(ds), ptr(rows), R, N, d,
                                     ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0, ptr(ws), wsb, stream_ptr(),
-                                    aux.cuda_stream), "star_scorer_bwd")
+                                    aux.cuda_stream if aux is not None else None), "star_scorer_bwd")
         t1, t2, t3, t4 = ctx.w_dtypes
         gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
         return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None)
