@@ -168,6 +168,22 @@ def main():
     frames_per_step = float(sum(lengths)) * world
     ms_per_step = elapsed / args.steps * 1e3
 
+    # for N > 1 also report the step without its gradient all-reduce (same K steps, same
+    # barrier / max-over-ranks bracket); `value` and `ms_per_step` above always include the all-reduce.
+    compute_ms = None
+    if world > 1:
+        sd.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+        torch.cuda.synchronize()
+        sd.barrier()
+        compute_ms = sd.max_over_ranks(time.perf_counter() - t1, dev) / args.steps * 1e3
+
     # ---- roofline of the dominant kernel: the fused scorer GEMM (gemm_nt_kernel<EPI_SCORE>), timed with
     # HIP events on the stream it is launched on.  Algorithmic FLOP per launch = N_f * (2 d^2 + 2 d).
     roofline = None
@@ -226,7 +242,9 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "frames": T, "d": d, "rate": rate,
                        "K": int(inp.key_len_dev(rate)[1]), "layers": nl, "heads": h, "tgt_len": L,
                        "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "grad_allreduce": "flat fp32 scorer grads, 1 per step" if world > 1 else None},
+                       "grad_allreduce": "flat fp32 scorer grads, 1 per step" if world > 1 else None,
+                       "compute_only_ms_per_step": compute_ms,
+                       "allreduce_ms_per_step": None if compute_ms is None else max(ms_per_step - compute_ms, 0.0)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
