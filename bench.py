@@ -103,12 +103,17 @@ def pmc_traffic(N, d):
 
 def main():
     args = parse()
+    if os.environ.get("STAR_BENCH_WATCHDOG"):       # debugging aid: dump the Python stacks if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STAR_BENCH_WATCHDOG"]), exit=True)
     from star_amd import dist as sd
     rank, local, world = sd.init()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("STAR_DIST_BACKEND") == "gloo":       # rehearsal: several ranks may share one card
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

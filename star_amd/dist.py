@@ -25,7 +25,8 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # STAR_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get("STAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -38,6 +39,17 @@ def shard(items: Sequence, rank: int, world: int) -> List:
     lo = (n * rank) // world
     hi = (n * (rank + 1)) // world
     return list(items[lo:hi])
+
+
+def _all_reduce(t: torch.Tensor, op):
+    """RCCL all-reduce on the tensor itself; under the gloo rehearsal backend a device tensor is staged through the
+    host (gloo's device-tensor path hangs when two ranks share one card)."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
 
 
 class FlatGradAllReduce:
@@ -66,7 +78,7 @@ class FlatGradAllReduce:
             views.append(v)
             o += n
         if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            _all_reduce(self.flat, dist.ReduceOp.SUM)
             self.flat.div_(world)
         for p, v in zip(self.params, views):
             if p.grad is None:
@@ -80,7 +92,7 @@ def max_over_ranks(x: float, device) -> float:
     if not dist.is_initialized():
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
