@@ -20,6 +20,7 @@ Reference lines restated (all paths relative to the reference checkout):
   resize                      src/models/w2v_simul.py:504-535
   fire_scan / block mask      src/models/w2v_simul.py:196-220,376-403
   xattn_core                  src/models/my_transformer.py:535-603
+  cif_aggregate               src/models/w2v_simul.py:558-606, w2v_asr.py:681-722  
 """
 from __future__ import annotations
 
@@ -245,6 +246,46 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
         a = a + s[:, None, None, :].to(a.dtype)
     p = torch.softmax(a, dim=-1)
     return p @ v, p
+
+
+# ------------------------------------------------------------------ 8f-2: CIF weighted aggregation
+def cif_aggregate(alphas: torch.Tensor, s: torch.Tensor, threshold: float = 1.0):
+    """Continuous integrate-and-fire weighted aggregation (w2v_simul.py:558-606; same loop at w2v_asr.py:681-722).
+
+    Serial fp32 recurrence per utterance: dc = 1 - I; I += a_t; fire = I >= thr; I -= 1 where fired;
+    cur = dc where fired else a_t; rem = a_t - cur; frame += cur * s_t; the frame is EMITTED at a fire and restarts
+    as rem * s_t.  Unlike the nugget fire scan there is no forced fire at the last valid frame, and the partial
+    segment after the last fire is dropped.  Differentiable w.r.t. alphas and s (fire decisions are constants).
+    Returns (cif_repr [B,Kf,d], cif_mask [B,Kf] fp32 0/1, fired_positions [B,Kf] int64 ascending, -1 padded)."""
+    bsz, t_len = alphas.shape
+    integ = alphas.new_zeros(bsz)
+    frame = s.new_zeros(bsz, s.shape[-1])
+    frames, fired = [], []
+    for t in range(t_len):
+        a = alphas[:, t]
+        dc = 1.0 - integ
+        integ = integ + a
+        fire = integ >= threshold
+        integ = torch.where(fire, integ - 1.0, integ)
+        cur = torch.where(fire, dc, a)
+        rem = a - cur
+        frame = frame + cur[:, None] * s[:, t, :]
+        frames.append(frame)
+        frame = torch.where(fire[:, None], rem[:, None] * s[:, t, :], frame)
+        fired.append(fire)
+    frames = torch.stack(frames, 1)
+    fired = torch.stack(fired, 1)
+    counts = fired.sum(1)
+    kf = int(counts.max())
+    rows, pos_all = [], torch.full((bsz, kf), -1, dtype=torch.int64)
+    mask = alphas.new_zeros(bsz, kf)
+    for b in range(bsz):
+        pos = torch.where(fired[b])[0]
+        sel = frames[b].index_select(0, pos)
+        rows.append(torch.cat([sel, s.new_zeros(kf - pos.numel(), s.shape[-1])], 0))
+        pos_all[b, :pos.numel()] = pos
+        mask[b, :pos.numel()] = 1
+    return torch.stack(rows, 0), mask, pos_all
 
 
 # ------------------------------------------------------------------ composite step (bench/smoke)

@@ -307,6 +307,78 @@ def _run_e2e(kind, use_ilk, seed):
     save(f"e2e_{kind}" + ("_ilk" if use_ilk else ""), **out)
 
 
+def gen_cif_agg():
+    """the reference's CIF weighted aggregation at its call site
+    (W2VSimulModel.lm_cif_training, w2v_simul.py:536-621), run with a tiny real decoder: records the resized alphas,
+    the semantic states, the aggregated memory handed to the decoder, and the gradients of all three."""
+    from transformers import GPT2Config
+    _compat_patches()
+    for seed, lengths, tlen in ((201, [40, 29], [12, 9]), (202, [37, 40, 5], [10, 14, 2])):
+        g = torch.Generator().manual_seed(seed)
+        d, T, L, V, nl = 512, 40, 14, 37, 1
+        B = len(lengths)
+        mask = len_mask(lengths, T)
+        x = torch.randn(B, T, d, generator=g)
+        cls = w2v_simul.W2VSimulModel
+        m = cls.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.nugget_model = torch.nn.Sequential(torch.nn.Linear(d, d), torch.nn.ReLU(inplace=True), torch.nn.Linear(d, 1))
+        with torch.no_grad():
+            for prm in m.nugget_model.parameters():
+                prm.copy_((torch.rand(prm.shape, generator=g) * 2 - 1) / d ** 0.5)
+        m.encoder = _FakeEncoder(x, mask)
+        sem = _FakeSemantic(d, g)
+        keep = {}
+        orig_sem = sem.forward
+
+        def sem_forward(inputs_embeds=None, attention_mask=None):
+            out = orig_sem(inputs_embeds=inputs_embeds, attention_mask=attention_mask)
+            out.last_hidden_state.retain_grad()
+            keep["s"] = out.last_hidden_state
+            return out
+
+        sem.forward = sem_forward
+        m.semantic_encoder = sem
+        cfg = GPT2Config(n_embd=d, vocab_size=V, num_labels=V, n_positions=64, pad_token_id=0, bos_token_id=1,
+                         eos_token_id=2, n_layer=nl, n_head=8, add_cross_attention=True, attn_pdrop=0.0, resid_pdrop=0.0,
+                         embd_pdrop=0.0)
+        torch.manual_seed(seed)
+        m.lm_decoder = my_transformer.MyGPT2ForLM(cfg)
+        for mod in m.lm_decoder.modules():
+            if isinstance(mod, my_transformer.MyGPT2Attention) and not getattr(mod, "is_cross_attention", False) \
+                    and not hasattr(mod, "bias"):
+                mod.register_buffer("bias", torch.tril(torch.ones(64, 64, dtype=torch.bool)).view(1, 1, 64, 64),
+                                    persistent=False)
+        m.train()
+        orig_resize = m.resize
+
+        def resize_spy(alphas, target_lengths, noise=0.0, threshold=1.0):
+            out = orig_resize(alphas, target_lengths=target_lengths, noise=noise, threshold=threshold)
+            out.retain_grad()
+            keep["alphas"] = out
+            return out
+
+        m.resize = resize_spy
+        orig_dec = m.lm_decoder.forward
+
+        def dec_spy(*a, **kw):
+            kw["encoder_hidden_states"].retain_grad()
+            keep["cif"] = kw["encoder_hidden_states"]
+            keep["cif_mask"] = kw["encoder_attention_mask"]
+            return orig_dec(*a, **kw)
+
+        m.lm_decoder.forward = dec_spy
+        text = torch.randint(3, V, (B, L), generator=g)
+        lm_mask = len_mask(tlen, L)
+        labels = text.masked_fill(~lm_mask, -100)
+        misc = {}
+        loss, misc = m.lm_cif_training(torch.zeros(B, 1), mask, text, lm_mask.long(), labels, misc)
+        loss.backward()
+        save(f"cifagg_{seed}", alphas=keep["alphas"], s=keep["s"], lengths=np.array(lengths),
+             cif=keep["cif"], cif_mask=keep["cif_mask"], positions=misc["nugget_indices"],
+             dcif=keep["cif"].grad, ds=keep["s"].grad, dalphas=keep["alphas"].grad, loss=loss.detach())
+
+
 def gen_e2e():
     _run_e2e("asr", False, 101)
     _run_e2e("simul", False, 102)
@@ -315,6 +387,6 @@ def gen_e2e():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e):
+    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg):
         if not only or fn.__name__ in only:
             fn()

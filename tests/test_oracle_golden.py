@@ -217,3 +217,20 @@ def test_e2e_call_sites(name):
     np.testing.assert_allclose(w[2].grad.numpy(), g["dw2"], rtol=1e-3, atol=1e-8)
     # db2 = sum of dscores: analytically 0 in the ASR path (softmax is shift invariant), so bound it by the terms
     np.testing.assert_allclose(w[3].grad.numpy(), g["db2"], rtol=1e-3, atol=1e-5 * np.abs(g["dscores"]).sum())
+
+
+# ------------------------------------------------------------------ 8f-2: CIF weighted aggregation
+@pytest.mark.parametrize("name", ["cifagg_201", "cifagg_202"])
+def test_cif_aggregate_golden(name):
+    """Reference call site W2VSimulModel.lm_cif_training (w2v_simul.py:558-606): aggregated memory, its mask, the
+    fired positions, and the gradients w.r.t. the semantic states and the (resized) alphas."""
+    g = load(name)
+    alphas = torch.from_numpy(g["alphas"]).clone().requires_grad_()
+    s = torch.from_numpy(g["s"]).clone().requires_grad_()
+    cif, mask, pos = orc.cif_aggregate(alphas, s)
+    np.testing.assert_array_equal(pos.numpy(), g["positions"])
+    np.testing.assert_array_equal(mask.numpy(), g["cif_mask"])
+    np.testing.assert_allclose(cif.detach().numpy(), g["cif"], rtol=1e-6, atol=1e-7)
+    (cif * torch.from_numpy(g["dcif"])).sum().backward()
+    np.testing.assert_allclose(s.grad.numpy(), g["ds"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(alphas.grad.numpy(), g["dalphas"], rtol=1e-4, atol=1e-8)
