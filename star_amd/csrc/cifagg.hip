@@ -1,0 +1,278 @@
+// CIF (continuous integrate-and-fire) weighted aggregation -- SURVEY.md section 8f item 2.
+//
+// Reference: the frame loop of W2VSimulModel.lm_cif_training (src/models/w2v_simul.py:558-606; the same loop in
+// W2VASRModel.lm_cif_training, w2v_asr.py:681-722): T Python iterations, each a handful of [B] / [B,H] launches,
+// then a per-utterance index_select + pad.  Restated:
+//     dc = 1 - I;  I += a_t;  fire = I >= thr;  I -= 1 where fired;  cur = fire ? dc : a_t;  rem = a_t - cur
+//     frame += cur * s_t;  emit frame at a fire;  frame = rem * s_t after a fire
+// (no forced fire at the last valid frame; the partial segment after the last fire is dropped).
+//
+// Here: (1) cif_weights_kernel -- the scalar recurrence, lane = utterance (64 serial fp32 recurrences side by side on
+// LDS-transposed 64-frame tiles, as in the nugget fire scan), emits cur / rem / segment id per frame and the fire
+// positions; (2) cif_aggregate_fwd_kernel -- one workgroup per emitted row walks its frames once, fp32 accumulate in
+// the reference's order (mul then add, no contraction); (3) backward: one wave per frame forms dS_t and the two
+// dot products <s_t, dOut> that are d cur_t / d rem_t, then a per-utterance reverse scan turns them into d alphas
+// (cur_t of a firing frame is 1 - sum of ALL earlier alphas + const, so its gradient reaches every earlier frame).
+// HBM traffic: forward reads S once (+ the firing rows twice), backward reads S once and writes dS once.
+#include "common.h"
+
+namespace star {
+
+constexpr int CW_TILE = 64;
+
+__global__ __launch_bounds__(64) void cif_weights_kernel(const float* __restrict__ alphas, float threshold, int B, int T,
+                                                        int cap, float* __restrict__ cur_out, float* __restrict__ rem_out,
+                                                        int32_t* __restrict__ seg_out, int64_t* __restrict__ idx_out,
+                                                        uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ max_count) {
+    __shared__ float t_in[CW_TILE * (CW_TILE + 1)];
+    __shared__ float t_cur[CW_TILE * (CW_TILE + 1)];
+    __shared__ float t_rem[CW_TILE * (CW_TILE + 1)];
+    __shared__ int32_t t_seg[CW_TILE * (CW_TILE + 1)];
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * 64;
+    const int nrows = min(64, B - b0);
+    const bool active = lane < nrows;
+    const int b = b0 + lane;
+
+    float integ = 0.0f;
+    int nfire = 0;
+    for (int t0 = 0; t0 < T; t0 += CW_TILE) {
+        __syncthreads();
+        for (int r = 0; r < nrows; ++r) {
+            const int t = t0 + lane;
+            t_in[r * (CW_TILE + 1) + lane] = (t < T) ? alphas[(size_t)(b0 + r) * T + t] : 0.0f;
+        }
+        __syncthreads();
+        const int steps = min(CW_TILE, T - t0);
+        if (active) {
+            for (int k = 0; k < steps; ++k) {
+                const float a = t_in[lane * (CW_TILE + 1) + k];
+                const float dc = __fsub_rn(1.0f, integ);
+                integ = __fadd_rn(integ, a);
+                const bool fire = integ >= threshold;
+                integ = fire ? __fsub_rn(integ, 1.0f) : integ;
+                const float c = fire ? dc : a;
+                t_cur[lane * (CW_TILE + 1) + k] = c;
+                t_rem[lane * (CW_TILE + 1) + k] = __fsub_rn(a, c);
+                t_seg[lane * (CW_TILE + 1) + k] = (nfire << 1) | (fire ? 1 : 0);
+                if (fire) {
+                    if (nfire < cap) {
+                        idx_out[(size_t)b * cap + nfire] = t0 + k;
+                        if (mask_out) mask_out[(size_t)b * cap + nfire] = 1;
+                    }
+                    ++nfire;
+                }
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < nrows; ++r) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const size_t o = (size_t)(b0 + r) * T + t;
+                cur_out[o] = t_cur[r * (CW_TILE + 1) + lane];
+                rem_out[o] = t_rem[r * (CW_TILE + 1) + lane];
+                seg_out[o] = t_seg[r * (CW_TILE + 1) + lane];
+            }
+        }
+    }
+    if (active) {
+        for (int j = nfire; j < cap; ++j) {
+            idx_out[(size_t)b * cap + j] = -1;
+            if (mask_out) mask_out[(size_t)b * cap + j] = 0;
+        }
+        counts[b] = nfire;
+    }
+    int m = active ? nfire : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if (lane == 0 && max_count) atomicMax(max_count, m);
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<__bf16>(const __bf16* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<__bf16>(__bf16* p, float v) { *p = (__bf16)v; }
+
+// out[b, j, :] = rem[f_{j-1}] * s[f_{j-1}] + sum_{t = f_{j-1}+1 .. f_j} cur[t] * s[t]   (f_{-1}: none, start at frame 0)
+// One workgroup per (b, j); thread = VEC consecutive channels; frames in ascending order, mul and add rounded
+// separately like the reference's `frame += cur[:, None] * s_t`.
+template <typename T, int VEC>
+__global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restrict__ s, const float* __restrict__ cur,
+                                                               const float* __restrict__ rem,
+                                                               const int64_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ counts, int Tn, int cap, int d,
+                                                               T* __restrict__ out) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int cnt = min(counts[b], cap);
+    T* orow = out + ((size_t)b * cap + j) * d;
+    if (j >= cnt) {
+        for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) st1<T>(orow + c + v, 0.0f);
+        return;
+    }
+    const int t_end = (int)idx[(size_t)b * cap + j];
+    const int t_prev = (j > 0) ? (int)idx[(size_t)b * cap + j - 1] : -1;
+    const T* sb = s + (size_t)b * Tn * d;
+    const float* cb = cur + (size_t)b * Tn;
+    for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC) {
+        float acc[VEC];
+        if (t_prev >= 0) {
+            const float w = rem[(size_t)b * Tn + t_prev];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = __fmul_rn(w, ld1<T>(sb + (size_t)t_prev * d + c + v));
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+        }
+        for (int t = t_prev + 1; t <= t_end; ++t) {
+            const float w = cb[t];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, ld1<T>(sb + (size_t)t * d + c + v)));
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) st1<T>(orow + c + v, acc[v]);
+    }
+}
+
+// One wave per frame (b, t):  dS_t = cur_t * g1 + rem_t * g2,  dcur_t = <s_t, g1>,  drem_t = <s_t, g2>
+// with g1 = dOut[b, seg_t] (if that row was emitted) and g2 = dOut[b, seg_t + 1] (if t fired and that row exists).
+template <typename T>
+__global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ s,
+                                                               const float* __restrict__ cur,
+                                                               const float* __restrict__ rem,
+                                                               const int32_t* __restrict__ seg,
+                                                               const int32_t* __restrict__ counts, int B, int Tn, int cap,
+                                                               int d, T* __restrict__ ds, float* __restrict__ dcur,
+                                                               float* __restrict__ drem) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * Tn) return;
+    const int b = (int)(row / Tn);
+    const int cnt = min(counts[b], cap);
+    const int enc = seg[row];
+    const int j = enc >> 1;
+    const bool fire = enc & 1;
+    const bool has1 = j < cnt, has2 = fire && (j + 1 < cnt);
+    const float c = cur[row], r = rem[row];
+    const T* srow = s + row * d;
+    const T* g1 = dout + ((size_t)b * cap + (has1 ? j : 0)) * d;
+    const T* g2 = dout + ((size_t)b * cap + (has2 ? j + 1 : 0)) * d;
+    T* drow = ds + row * d;
+    float a1 = 0.f, a2 = 0.f;
+    for (int ch = lane; ch < d; ch += 64) {
+        const float sv = ld1<T>(srow + ch);
+        const float v1 = has1 ? ld1<T>(g1 + ch) : 0.f;
+        const float v2 = has2 ? ld1<T>(g2 + ch) : 0.f;
+        a1 += sv * v1;
+        a2 += sv * v2;
+        st1<T>(drow + ch, c * v1 + r * v2);
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+        dcur[row] = a1;
+        drem[row] = a2;
+    }
+}
+
+// d alpha_u = (fire_u ? drem_u : dcur_u) + sum_{t > u, fire_t} (drem_t - dcur_t): reverse scan, one wave per utterance
+__global__ __launch_bounds__(64) void cif_dalpha_kernel(const float* __restrict__ dcur, const float* __restrict__ drem,
+                                                       const int32_t* __restrict__ seg, int Tn,
+                                                       float* __restrict__ dalphas) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float carry = 0.f;      // sum over firing frames beyond the current chunk
+    const int nchunks = (Tn + 63) / 64;
+    for (int cidx = nchunks - 1; cidx >= 0; --cidx) {
+        const int t = cidx * 64 + lane;
+        const bool ok = t < Tn;
+        const size_t o = (size_t)b * Tn + (ok ? t : 0);
+        const bool fire = ok && (seg[o] & 1);
+        const float dc = ok ? dcur[o] : 0.f, dr = ok ? drem[o] : 0.f;
+        const float v = fire ? (dr - dc) : 0.f;
+        // inclusive suffix sum over the lanes (lane 63 = latest frame of the chunk)
+        float incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float n = __shfl_down(incl, off, 64);
+            if (lane + off < 64) incl += n;
+        }
+        if (ok) dalphas[o] = (fire ? dr : dc) + (incl - v) + carry;
+        carry += __shfl(incl, 0, 64);
+    }
+}
+
+}  // namespace star
+
+extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int T, int cap, float* cur, float* rem,
+                                int32_t* seg, int64_t* idx_out, uint8_t* mask_out, int32_t* counts, int32_t* max_count,
+                                void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alphas && cur && rem && seg && idx_out && counts, "star_cif_weights: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1, "star_cif_weights: bad shape B=%d T=%d cap=%d", B, T, cap);
+    if (max_count) {
+        hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            set_error("star_cif_weights: memset failed: %s", hipGetErrorString(e));
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(cif_weights_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, alphas, threshold, B, T,
+                       cap, cur, rem, seg, idx_out, mask_out, counts, max_count);
+    STAR_LAUNCH_CHECK("star_cif_weights");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_aggregate_fwd(const void* s, int dtype, const float* cur, const float* rem, const int64_t* idx,
+                                      const int32_t* counts, int B, int T, int cap, int d, void* out, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(s && cur && rem && idx && counts && out, "star_cif_aggregate_fwd: null pointer");
+    STAR_REQUIRE(B >= 1 && B <= 65535 && T >= 1 && cap >= 1 && d >= 1, "star_cif_aggregate_fwd: bad shape");
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_cif_aggregate_fwd: dtype must be bf16 or f32");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cap, B);
+    if (dtype == STAR_DT_BF16) {
+        if (d % 8 == 0)
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 8>), grid, dim3(128), 0, st, (const __bf16*)s, cur, rem,
+                               idx, counts, T, cap, d, (__bf16*)out);
+        else
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 1>), grid, dim3(128), 0, st, (const __bf16*)s, cur, rem,
+                               idx, counts, T, cap, d, (__bf16*)out);
+    } else {
+        if (d % 4 == 0)
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 4>), grid, dim3(128), 0, st, (const float*)s, cur, rem, idx,
+                               counts, T, cap, d, (float*)out);
+        else
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 1>), grid, dim3(128), 0, st, (const float*)s, cur, rem, idx,
+                               counts, T, cap, d, (float*)out);
+    }
+    STAR_LAUNCH_CHECK("star_cif_aggregate_fwd");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const float* cur, const float* rem,
+                                      const int32_t* seg, const int32_t* counts, int B, int T, int cap, int d, void* ds,
+                                      float* dalphas, float* workspace, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(dout && s && cur && rem && seg && counts && ds && dalphas && workspace,
+                 "star_cif_aggregate_bwd: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1 && d >= 1, "star_cif_aggregate_bwd: bad shape");
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_cif_aggregate_bwd: dtype must be bf16 or f32");
+    hipStream_t st = (hipStream_t)stream;
+    float* dcur = workspace;
+    float* drem = workspace + (size_t)B * T;
+    const int64_t rows = (int64_t)B * T;
+    if (dtype == STAR_DT_BF16)
+        hipLaunchKernelGGL((cif_aggregate_bwd_kernel<__bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const __bf16*)dout,
+                           (const __bf16*)s, cur, rem, seg, counts, B, T, cap, d, (__bf16*)ds, dcur, drem);
+    else
+        hipLaunchKernelGGL((cif_aggregate_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)dout,
+                           (const float*)s, cur, rem, seg, counts, B, T, cap, d, (float*)ds, dcur, drem);
+    hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(64), 0, st, (const float*)dcur, (const float*)drem, seg, T,
+                       dalphas);
+    STAR_LAUNCH_CHECK("star_cif_aggregate_bwd");
+    return STAR_OK;
+}

@@ -89,6 +89,15 @@ class NuggetOpsMixin:
         return ops.cif_resize(alphas, target_lengths, threshold=threshold)
 
     @staticmethod
+    def cif_weighted_aggregate(alphas: torch.Tensor, semantic_repr: torch.Tensor, threshold: float = 1.0):
+        """The integrate-and-fire frame loop of lm_cif_training (w2v_simul.py:558-606; w2v_asr.py:681-722) as one
+        call: -> (cif_repr [B,Kf,d], cif_attn_mask [B,Kf] fp32 0/1, fired positions [B,Kf] int64 with -1 pads),
+        Kf = max number of fires (read back to size the outputs, as the reference does with num_fires.max())."""
+        cif, mask, idx, counts, mx = ops.cif_aggregate(alphas, semantic_repr, threshold=threshold)
+        kf = max(int(mx.item()), 0)
+        return cif[:, :kf], mask[:, :kf].to(torch.float32), idx[:, :kf]
+
+    @staticmethod
     def get_valid_mask_indices(mask: torch.Tensor, padding_value: int = -1):
         """w2v_simul.py:196-220: ascending positions of the True entries, padded; -> (indices, max_valid, n)."""
         assert len(mask.shape) <= 2, f"Only supports 1D or 2D tensors - got {len(mask.shape)}."

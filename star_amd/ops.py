@@ -316,6 +316,65 @@ class ActiveRows:
         self.rows = None
 
 
+# ----------------------------------------------------------------------------- 8f-2
+class _CifAggregate(torch.autograd.Function):
+    """CIF weighted aggregation (lm_cif_training frame loop, w2v_simul.py:558-606 / w2v_asr.py:681-722)."""
+
+    @staticmethod
+    def forward(ctx, alphas, s, threshold, cap):
+        ctx.set_materialize_grads(False)
+        B, T, d = s.shape
+        dev = s.device
+        a = alphas.detach().to(torch.float32).contiguous()
+        sc = s.detach().contiguous()
+        cur = torch.empty((B, T), dtype=torch.float32, device=dev)
+        rem = torch.empty((B, T), dtype=torch.float32, device=dev)
+        seg = torch.empty((B, T), dtype=torch.int32, device=dev)
+        idx = torch.empty((B, cap), dtype=torch.int64, device=dev)
+        mask = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        mx = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(lib().star_cif_weights(ptr(a), float(threshold), B, T, cap, ptr(cur), ptr(rem), ptr(seg), ptr(idx),
+                                     ptr(mask), ptr(counts), ptr(mx), stream_ptr()), "star_cif_weights")
+        out = torch.empty((B, cap, d), dtype=sc.dtype, device=dev)
+        dt = DT_BF16 if sc.dtype == torch.bfloat16 else DT_F32
+        check(lib().star_cif_aggregate_fwd(ptr(sc), dt, ptr(cur), ptr(rem), ptr(idx), ptr(counts), B, T, cap, d, ptr(out),
+                                           stream_ptr()), "star_cif_aggregate_fwd")
+        ctx.save_for_backward(sc, cur, rem, seg, counts)
+        ctx.cap = cap
+        ctx.a_dtype = alphas.dtype
+        ctx.mark_non_differentiable(idx, mask, counts, mx)
+        return out, mask, idx, counts, mx
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        if g is None:
+            return None, None, None, None
+        sc, cur, rem, seg, counts = ctx.saved_tensors
+        B, T, d = sc.shape
+        gc = g.to(sc.dtype).contiguous()
+        ds = torch.empty_like(sc)
+        da = torch.empty((B, T), dtype=torch.float32, device=sc.device)
+        ws = torch.empty((2 * B * T,), dtype=torch.float32, device=sc.device)
+        dt = DT_BF16 if sc.dtype == torch.bfloat16 else DT_F32
+        check(lib().star_cif_aggregate_bwd(ptr(gc), ptr(sc), dt, ptr(cur), ptr(rem), ptr(seg), ptr(counts), B, T, ctx.cap,
+                                           d, ptr(ds), ptr(da), ptr(ws), stream_ptr()), "star_cif_aggregate_bwd")
+        return da.to(ctx.a_dtype), ds, None, None
+
+
+def cif_aggregate(alphas, s, threshold: float = 1.0, cap: Optional[int] = None):
+    """alphas [B,T] (masked, resized), s [B,T,d] bf16/fp32 -> (cif_repr [B,cap,d], cif_mask [B,cap] uint8,
+    fired_positions [B,cap] int64 (-1 padded), counts [B] int32, max_count [1] int32).  Differentiable w.r.t. alphas
+    and s.  `cap` (>= the largest fire count) avoids a device->host sync; when None it is T (then trim with
+    max_count, as the reference sizes its output with num_fires.max())."""
+    _need_cuda(alphas, s)
+    if s.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"cif_aggregate: unsupported dtype {s.dtype}")
+    if alphas.shape != s.shape[:2]:
+        raise ValueError(f"cif_aggregate: alphas {tuple(alphas.shape)} does not match states {tuple(s.shape)}")
+    return _CifAggregate.apply(alphas, s, float(threshold), int(cap if cap is not None else s.shape[1]))
+
+
 _AUX_STREAMS = {}
 
 

@@ -577,3 +577,56 @@ def test_e2e_call_sites_gpu(ops, name):
     # the individual terms do not cancel, so the bar is relative to sum |dscores| (measured 1.3e-3 of it)
     np.testing.assert_allclose(scorer[2].bias.grad.cpu().numpy(), ref_db2, rtol=2e-2,
                                atol=5e-3 * np.abs(g["dscores"]).sum())
+
+
+# ------------------------------------------------------------------------------------------------ 8f-2: CIF aggregation
+@pytest.mark.parametrize("name", ["cifagg_201", "cifagg_202"])
+def test_cif_aggregate_golden_gpu(ops, name):
+    """Reference call site lm_cif_training (w2v_simul.py:558-606): positions / mask integer-exact; fp32 states: output
+    within 1 ulp (same accumulation order), gradients rtol 1e-4 (summation order differs)."""
+    from star_amd.nugget import NuggetOpsMixin
+    g = load(name)
+    alphas = dev(g["alphas"]).requires_grad_()
+    s = dev(g["s"]).requires_grad_()
+    cif, mask, pos = NuggetOpsMixin.cif_weighted_aggregate(alphas, s)
+    np.testing.assert_array_equal(pos.cpu().numpy(), g["positions"])
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["cif_mask"])
+    np.testing.assert_allclose(cif.detach().cpu().numpy(), g["cif"], rtol=1e-6, atol=2e-7)     # measured: <= 1 ulp
+    cif.backward(dev(g["dcif"]))
+    np.testing.assert_allclose(s.grad.cpu().numpy(), g["ds"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(alphas.grad.cpu().numpy(), g["dalphas"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,T,d,dtype", [(5, 300, 768, torch.bfloat16), (70, 129, 64, torch.float32),
+                                         (2, 1500, 1024, torch.bfloat16), (3, 65, 100, torch.float32)])
+def test_cif_aggregate_random_vs_oracle(ops, B, T, d, dtype):
+    rng = np.random.default_rng(B + T + d)
+    lengths = rng.integers(1, T + 1, size=B)
+    lengths[0] = T
+    mask = lmask(lengths, T)
+    alphas_np = (rng.random((B, T)).astype(np.float32) * 0.4) * mask        # a fire every ~5 frames
+    alphas_np[B - 1] *= 0.001                                                # a row that never fires
+    s_np = rng.standard_normal((B, T, d)).astype(np.float32)
+    s_ref = torch.from_numpy(s_np).to(dtype).float().requires_grad_()        # oracle on the rounded states
+    a_ref = torch.from_numpy(alphas_np).clone().requires_grad_()
+    o_cif, o_mask, o_pos = orc.cif_aggregate(a_ref, s_ref)
+    a = dev(alphas_np).requires_grad_()
+    s = dev(s_np, dtype).requires_grad_()
+    cif, cmask, idx, counts, mx = ops.cif_aggregate(a, s, cap=T)
+    kf = o_pos.shape[1]
+    assert int(mx.item()) == kf
+    np.testing.assert_array_equal(idx[:, :kf].cpu().numpy(), o_pos.numpy())
+    assert (idx[:, kf:] == -1).all() and (cif[:, kf:] == 0).all()
+    np.testing.assert_array_equal(cmask[:, :kf].cpu().numpy(), o_mask.numpy().astype(np.uint8))
+    tol = dict(rtol=1e-2, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cif[:, :kf].detach().float().cpu().numpy(), o_cif.detach().numpy(), **tol)
+    gout = torch.from_numpy(rng.standard_normal((B, kf, d)).astype(np.float32)).to(dtype)
+    (o_cif * gout.float()).sum().backward()
+    gfull = torch.zeros(B, T, d, dtype=dtype)
+    gfull[:, :kf] = gout
+    cif.backward(gfull.to(DEV))
+    gtol = dict(rtol=2e-2, atol=2e-2 * float(s_ref.grad.abs().max())) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s.grad.float().cpu().numpy(), s_ref.grad.numpy(), **gtol)
+    atol_a = (2e-2 if dtype == torch.bfloat16 else 1e-4) * float(a_ref.grad.abs().max())
+    np.testing.assert_allclose(a.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=atol_a)
