@@ -133,21 +133,22 @@ int star_cif_block_mask(const int64_t* idx, const int32_t* counts, const uint8_t
  * at the last valid frame; the partial segment after the last fire is dropped (as in the reference).
  *
  * star_cif_weights: the scalar recurrence.  alphas [B,T] fp32 (already masked / resized).
- *   Outputs: cur, rem [B,T] fp32; seg [B,T] int32 = (number of fires before t) << 1 | fired(t);
- *   idx_out [B,cap] int64 ascending fire positions, -1 padded; mask_out [B,cap] uint8 or NULL; counts [B] int32
- *   (fires beyond cap are dropped but counted); max_count [1] int32 or NULL. */
-int star_cif_weights(const float* alphas, float threshold, int B, int T, int cap, float* cur, float* rem,
-                     int32_t* seg, int64_t* idx_out, uint8_t* mask_out, int32_t* counts,
-                     int32_t* max_count, void* stream);
+ *   Outputs: weights [B,T,4] fp32, 16-byte aligned, one record per frame {cur, rem, bits of the int32
+ *   (number of fires before t) << 1 | fired(t), 0}; idx_out [B,cap] int64 ascending fire positions, -1 padded;
+ *   mask_out [B,cap] uint8 or NULL; counts [B] int32 (fires beyond cap are dropped but counted);
+ *   max_count [1] int32 or NULL.  T <= 16384. */
+int star_cif_weights(const float* alphas, float threshold, int B, int T, int cap, float* weights,
+                     int64_t* idx_out, uint8_t* mask_out, int32_t* counts, int32_t* max_count,
+                     void* stream);
 /* out[b,j,:] = rem[f_{j-1}] s[f_{j-1}] + sum_{t=f_{j-1}+1..f_j} cur[t] s[t] for j < min(counts[b], cap), else 0;
  * fp32 accumulation in frame order, product and sum rounded separately.  s [B,T,d], out [B,cap,d], dtype
- * STAR_DT_BF16 or STAR_DT_F32 (both tensors). */
-int star_cif_aggregate_fwd(const void* s, int dtype, const float* cur, const float* rem, const int64_t* idx,
+ * STAR_DT_BF16 or STAR_DT_F32 (both tensors); weights / idx / counts as written by star_cif_weights. */
+int star_cif_aggregate_fwd(const void* s, int dtype, const float* weights, const int64_t* idx,
                            const int32_t* counts, int B, int T, int cap, int d, void* out, void* stream);
 /* Backward: ds [B,T,d] (every frame written), dalphas [B,T] fp32 (fire decisions are constants; the gradient of
  * a firing frame's weight reaches every earlier alpha).  workspace: 2*B*T floats. */
-int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const float* cur, const float* rem,
-                           const int32_t* seg, const int32_t* counts, int B, int T, int cap, int d, void* ds,
+int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const float* weights,
+                           const int32_t* counts, int B, int T, int cap, int d, void* ds,
                            float* dalphas, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------- a1: scorer MLP

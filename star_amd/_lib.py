@@ -48,9 +48,9 @@ SIGNATURES = {
     "star_cif_resize": (_I, [_P, _P, _F, _I, _I, _I, _P, _P]),
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
-    "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "star_cif_aggregate_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "star_cif_aggregate_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "star_cif_aggregate_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "star_cif_aggregate_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "star_scorer_fwd_workspace": (_SZ, [_I64, _I]),
     "star_scorer_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "star_scorer_bwd_workspace": (_SZ, [_I64, _I]),

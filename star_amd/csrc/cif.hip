@@ -135,115 +135,107 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------ a7
-// One wave per 64 utterances, lane = utterance: the recurrence is inherently serial in t and
-// fp32 addition is not associative, so a parallel prefix sum cannot reproduce the reference's
-// fire positions; 64 recurrences run side by side instead.  Tiles of 64 frames are loaded
-// coalesced (lane = frame), transposed through LDS (pitch 65 dwords, conflict-free), and consumed
-// lane = row.  Fire flags leave the scan as bit words; the compaction into ascending positions is
-// integer work (popcount prefix over words).
-constexpr int FS_TILE = 64;
+// The recurrence is inherently serial in t and fp32 addition is not associative, so a parallel prefix sum cannot
+// reproduce the reference's fire positions: every utterance runs its own exact serial recurrence (one lane each).
+// What can be parallel is everything around it: a workgroup owns a few utterances, brings their whole rows into
+// LDS with all 256 threads (coalesced), then lane r walks row r from LDS in register blocks of 16 frames; fire
+// positions are written straight from the fire bits of a block, off the dependent chain.  (The first version,
+// 64 utterances per wave on LDS-transposed 64-frame tiles, spent its time waiting on one tile load per 64 steps:
+// 212 us at B = 32, T = 1500.)
 
-__global__ __launch_bounds__(64) void cif_fire_scan_kernel(
+// Rows per workgroup: the rows of a workgroup are resident in LDS as a whole (R * T floats, odd pitch), so the
+// serial part never touches global memory for its inputs; more, smaller workgroups = more recurrences in flight.
+static inline int scan_rows_per_wg(int T) {
+    int r = 8;
+    while (r > 1 && (size_t)r * (T | 1) * 4 > 64 * 1024) r >>= 1;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void cif_fire_scan_kernel(
     const float* __restrict__ alphas, const uint8_t* __restrict__ attn_mask, const int32_t* __restrict__ lengths,
-    const float* __restrict__ scores, int B, int T, int cap, int64_t* __restrict__ idx_out,
+    const float* __restrict__ scores, int B, int T, int cap, int R, int64_t* __restrict__ idx_out,
     uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
     float* __restrict__ scores_gather) {
-    extern __shared__ uint32_t fs_smem[];
-    const int nwords = (T + 31) / 32;
-    float* tile = (float*)fs_smem;                          // [64][65]
-    uint32_t* words = fs_smem + FS_TILE * (FS_TILE + 1);    // [64][nwords]
-    __shared__ int lens[64];
-    const int lane = threadIdx.x;
-    const int b0 = blockIdx.x * 64;
-    const int nrows = min(64, B - b0);
-    const int myrow = b0 + lane;
-    const bool active = lane < nrows;
-
-    // valid-frame count per row (== attn_mask.sum(1) of the reference)
-    if (attn_mask) {
-        for (int r = 0; r < nrows; ++r) {
-            int c = 0;
-            for (int i = lane; i < T; i += 64) c += (attn_mask[(size_t)(b0 + r) * T + i] != 0);
+    extern __shared__ float fs_rows[];            // [R][pitch] alphas * mask
+    __shared__ int lens[8], nfires[8];
+    const int pitch = T | 1;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * R;
+    const int nrows = min(R, B - b0);
+    if (tid < 8) lens[tid] = 0;
+    __syncthreads();
+    // phase 1 (all threads, coalesced): rows -> LDS, valid-frame counts (== attn_mask.sum(1) of the reference)
+    for (int r = 0; r < nrows; ++r) {
+        const size_t base = (size_t)(b0 + r) * T;
+        const int n_r = attn_mask ? 0 : min(lengths[b0 + r], T);
+        int c = 0;
+        for (int t = tid; t < T; t += 256) {
+            const float a = alphas[base + t];
+            const bool valid = attn_mask ? (attn_mask[base + t] != 0) : (t < n_r);
+            fs_rows[r * pitch + t] = valid ? a : a * 0.0f;     // alphas * attn_mask (keeps NaN/inf of the product)
+            c += valid ? 1 : 0;
+        }
+        if (attn_mask) {
             c = wave_sum(c);
-            if (lane == 0) lens[r] = c;
+            if ((tid & 63) == 0) atomicAdd(&lens[r], c);
+        } else if (tid == 0) {
+            lens[r] = n_r;
         }
-    } else if (active) {
-        lens[lane] = lengths[myrow];
     }
     __syncthreads();
-    const int n = active ? lens[lane] : 0;
-
-    float cur = 0.0f;
-    uint32_t bits = 0;
-    for (int t0 = 0; t0 < T; t0 += FS_TILE) {
-        __syncthreads();
-        // coalesced load: for each row r, lanes read 64 consecutive frames
-        for (int r = 0; r < nrows; ++r) {
-            int t = t0 + lane;
-            float a = 0.0f;
-            if (t < T) {
-                a = alphas[(size_t)(b0 + r) * T + t];
-                bool valid = attn_mask ? (attn_mask[(size_t)(b0 + r) * T + t] != 0) : (t < lens[r]);
-                a = valid ? a : a * 0.0f;   // alphas * attn_mask (keeps NaN/inf semantics of the product)
-            }
-            tile[r * (FS_TILE + 1) + lane] = a;
-        }
-        __syncthreads();
-        const int steps = min(FS_TILE, T - t0);
-        if (active) {
-            for (int k = 0; k < steps; ++k) {
+    // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r
+    if (tid < nrows) {
+        const int b = b0 + tid;
+        const int n = lens[tid];
+        const float* row = fs_rows + tid * pitch;
+        float cur = 0.0f;
+        int nf = 0;
+        for (int t0 = 0; t0 < T; t0 += 16) {
+            float a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (t0 + k < T) ? row[t0 + k] : 0.0f;
+            // per-frame threshold, computed off the dependent chain: 1 normally, -inf at the last valid frame (forced
+            // fire), +inf past T -- the chain itself is add -> compare -> select
+            float thr[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
                 const int t = t0 + k;
-                float a = tile[lane * (FS_TILE + 1) + k];
-                cur = __fadd_rn(cur, a);
-                bool fire = (cur >= 1.0f) || (n == t + 1);
+                thr[k] = (t >= T) ? __builtin_inff() : ((n == t + 1) ? -__builtin_inff() : 1.0f);
+            }
+            uint32_t fb = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                cur = __fadd_rn(cur, a[k]);
+                const bool fire = cur >= thr[k];
                 cur = fire ? __fsub_rn(cur, 1.0f) : cur;
-                bits |= (fire ? 1u : 0u) << (t & 31);
-                if ((t & 31) == 31 || t == T - 1) {
-                    words[lane * nwords + (t >> 5)] = bits;
-                    bits = 0;
+                fb |= (fire ? 1u : 0u) << k;
+            }
+            while (fb) {                                  // off the serial chain
+                const int t = t0 + __builtin_ctz(fb);
+                fb &= fb - 1;
+                if (nf < cap) {
+                    idx_out[(size_t)b * cap + nf] = t;
+                    if (mask_out) mask_out[(size_t)b * cap + nf] = 1;
+                    if (scores_gather) scores_gather[(size_t)b * cap + nf] = scores[(size_t)b * T + t];
                 }
+                ++nf;
             }
         }
+        nfires[tid] = nf;
+        if (counts) counts[b] = nf;
+        if (max_count) atomicMax(max_count, nf);
     }
     __syncthreads();
-    // compaction: the wave walks the rows, lane = bit word
-    int wave_max = 0;
+    // phase 3 (all threads): pad slots
     for (int r = 0; r < nrows; ++r) {
         const int b = b0 + r;
-        int base = 0;
-        for (int w0 = 0; w0 < nwords; w0 += 64) {
-            int w = w0 + lane;
-            uint32_t wb = (w < nwords) ? words[r * nwords + w] : 0u;
-            int pc = __popc(wb);
-            int incl = pc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int v = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += v;
-            }
-            int pos = base + incl - pc;
-            while (wb) {
-                int t = w * 32 + __builtin_ctz(wb);
-                wb &= wb - 1;
-                if (pos < cap) {
-                    idx_out[(size_t)b * cap + pos] = t;
-                    if (mask_out) mask_out[(size_t)b * cap + pos] = 1;
-                    if (scores_gather) scores_gather[(size_t)b * cap + pos] = scores[(size_t)b * T + t];
-                }
-                ++pos;
-            }
-            base += __shfl(incl, 63, 64);
-        }
         const float last_score = scores_gather ? scores[(size_t)b * T + (T - 1)] : 0.0f;
-        for (int j = base + lane; j < cap; j += 64) {
+        for (int j = nfires[r] + tid; j < cap; j += 256) {
             idx_out[(size_t)b * cap + j] = -1;
             if (mask_out) mask_out[(size_t)b * cap + j] = 0;
             if (scores_gather) scores_gather[(size_t)b * cap + j] = last_score;  // index -1 == frame T-1
         }
-        if (lane == 0 && counts) counts[b] = base;
-        wave_max = max(wave_max, base);
     }
-    if (lane == 0 && max_count) atomicMax(max_count, wave_max);
 }
 
 // block_attn_mask rows: out[b,i,j] = (prev_fire(i) < j <= i) && valid(i)
@@ -325,15 +317,21 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
     STAR_REQUIRE((attn_mask != nullptr) != (lengths != nullptr), "star_cif_fire_scan: give exactly one of attn_mask / lengths");
     STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1, "star_cif_fire_scan: bad shape B=%d T=%d cap=%d", B, T, cap);
     STAR_REQUIRE(!scores_gather || scores, "star_cif_fire_scan: scores_gather requested without scores");
-    const int nwords = (T + 31) / 32;
-    size_t smem = (size_t)(FS_TILE * (FS_TILE + 1) + 64 * nwords) * 4;
-    STAR_REQUIRE(smem <= 150 * 1024, "star_cif_fire_scan: T=%d needs %zu bytes of LDS", T, smem);
+    STAR_REQUIRE(T <= 16384, "star_cif_fire_scan: T=%d exceeds the 16384-frame LDS row limit", T);
+    const int R = scan_rows_per_wg(T);
+    const size_t smem = (size_t)R * (T | 1) * 4;
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)cif_fire_scan_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            set_error("star_cif_fire_scan: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
-            return STAR_ERR_LAUNCH;
+        static bool done[64] = {};
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (!done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void*)cif_fire_scan_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) {
+                set_error("star_cif_fire_scan: cannot reserve LDS: %s", hipGetErrorString(e));
+                return STAR_ERR_LAUNCH;
+            }
+            done[dev & 63] = true;
         }
     }
     if (max_count) {
@@ -343,8 +341,8 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
             return STAR_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(cif_fire_scan_kernel, dim3(cdiv(B, 64)), dim3(64), smem, (hipStream_t)stream, alphas, attn_mask,
-                       lengths, scores, B, T, cap, idx_out, mask_out, counts, max_count, scores_gather);
+    hipLaunchKernelGGL(cif_fire_scan_kernel, dim3(cdiv(B, R)), dim3(256), smem, (hipStream_t)stream, alphas, attn_mask,
+                       lengths, scores, B, T, cap, R, idx_out, mask_out, counts, max_count, scores_gather);
     STAR_LAUNCH_CHECK("star_cif_fire_scan");
     return STAR_OK;
 }

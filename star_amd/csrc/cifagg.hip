@@ -7,9 +7,8 @@
 //     frame += cur * s_t;  emit frame at a fire;  frame = rem * s_t after a fire
 // (no forced fire at the last valid frame; the partial segment after the last fire is dropped).
 //
-// Here: (1) cif_weights_kernel -- the scalar recurrence, lane = utterance (64 serial fp32 recurrences side by side on
-// LDS-transposed 64-frame tiles, as in the nugget fire scan), emits cur / rem / segment id per frame and the fire
-// positions; (2) cif_aggregate_fwd_kernel -- one workgroup per emitted row walks its frames once, fp32 accumulate in
+// Here: (1) cif_weights_kernel -- the scalar recurrence, one lane per utterance on rows resident in LDS (as in the
+// nugget fire scan), emits cur / rem / segment id per frame and the fire positions; (2) cif_aggregate_fwd_kernel -- one workgroup per emitted row walks its frames once, fp32 accumulate in
 // the reference's order (mul then add, no contraction); (3) backward: one wave per frame forms dS_t and the two
 // dot products <s_t, dOut> that are d cur_t / d rem_t, then a per-utterance reverse scan turns them into d alphas
 // (cur_t of a firing frame is 1 - sum of ALL earlier alphas + const, so its gradient reaches every earlier frame).
@@ -18,75 +17,90 @@
 
 namespace star {
 
-constexpr int CW_TILE = 64;
+static inline size_t cw_row_bytes(int T) { return (size_t)(2 * (T | 1) + ((T + 15) >> 4)) * 4; }
+static inline int cw_rows_per_wg(int T) {
+    int r = 4;
+    while (r > 1 && (size_t)r * cw_row_bytes(T) > 64 * 1024) r >>= 1;
+    return r;
+}
 
-__global__ __launch_bounds__(64) void cif_weights_kernel(const float* __restrict__ alphas, float threshold, int B, int T,
-                                                        int cap, float* __restrict__ cur_out, float* __restrict__ rem_out,
-                                                        int32_t* __restrict__ seg_out, int64_t* __restrict__ idx_out,
-                                                        uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts,
-                                                        int32_t* __restrict__ max_count) {
-    __shared__ float t_in[CW_TILE * (CW_TILE + 1)];
-    __shared__ float t_cur[CW_TILE * (CW_TILE + 1)];
-    __shared__ float t_rem[CW_TILE * (CW_TILE + 1)];
-    __shared__ int32_t t_seg[CW_TILE * (CW_TILE + 1)];
-    const int lane = threadIdx.x;
-    const int b0 = blockIdx.x * 64;
-    const int nrows = min(64, B - b0);
-    const bool active = lane < nrows;
-    const int b = b0 + lane;
-
-    float integ = 0.0f;
-    int nfire = 0;
-    for (int t0 = 0; t0 < T; t0 += CW_TILE) {
-        __syncthreads();
-        for (int r = 0; r < nrows; ++r) {
-            const int t = t0 + lane;
-            t_in[r * (CW_TILE + 1) + lane] = (t < T) ? alphas[(size_t)(b0 + r) * T + t] : 0.0f;
-        }
-        __syncthreads();
-        const int steps = min(CW_TILE, T - t0);
-        if (active) {
-            for (int k = 0; k < steps; ++k) {
-                const float a = t_in[lane * (CW_TILE + 1) + k];
-                const float dc = __fsub_rn(1.0f, integ);
-                integ = __fadd_rn(integ, a);
-                const bool fire = integ >= threshold;
-                integ = fire ? __fsub_rn(integ, 1.0f) : integ;
-                const float c = fire ? dc : a;
-                t_cur[lane * (CW_TILE + 1) + k] = c;
-                t_rem[lane * (CW_TILE + 1) + k] = __fsub_rn(a, c);
-                t_seg[lane * (CW_TILE + 1) + k] = (nfire << 1) | (fire ? 1 : 0);
-                if (fire) {
-                    if (nfire < cap) {
-                        idx_out[(size_t)b * cap + nfire] = t0 + k;
-                        if (mask_out) mask_out[(size_t)b * cap + nfire] = 1;
-                    }
-                    ++nfire;
-                }
-            }
-        }
-        __syncthreads();
-        for (int r = 0; r < nrows; ++r) {
-            const int t = t0 + lane;
-            if (t < T) {
-                const size_t o = (size_t)(b0 + r) * T + t;
-                cur_out[o] = t_cur[r * (CW_TILE + 1) + lane];
-                rem_out[o] = t_rem[r * (CW_TILE + 1) + lane];
-                seg_out[o] = t_seg[r * (CW_TILE + 1) + lane];
-            }
-        }
-    }
-    if (active) {
-        for (int j = nfire; j < cap; ++j) {
-            idx_out[(size_t)b * cap + j] = -1;
-            if (mask_out) mask_out[(size_t)b * cap + j] = 0;
-        }
-        counts[b] = nfire;
-    }
-    int m = active ? nfire : 0;
+// A workgroup owns R utterances.  (1) all 256 threads bring their alpha rows into LDS (coalesced); (2) lane r runs
+// the exact serial recurrence of row r from LDS in register blocks of 16 frames, keeping ONLY what is serial on the
+// dependent chain (integral, fire bit): it leaves 1 - I_before per frame, the fire bits and the fire count before
+// every block in LDS and writes the fire positions; (3) all threads turn that into the per-frame records
+// {cur, rem, segment/fire bits} in parallel (coalesced 16-byte stores).
+__global__ __launch_bounds__(256) void cif_weights_kernel(const float* __restrict__ alphas, float threshold, int B, int T,
+                                                         int cap, int R, f32x4* __restrict__ w_out,
+                                                         int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ max_count) {
+    extern __shared__ float cw_smem[];
+    const int pitch = T | 1;
+    const int nblk = (T + 15) >> 4;
+    float* a_rows = cw_smem;                                  // [R][pitch] alphas
+    float* dc_rows = a_rows + R * pitch;                      // [R][pitch] 1 - integral before the frame
+    uint32_t* blk = (uint32_t*)(dc_rows + R * pitch);         // [R][nblk] fire bits (low 16) | fires before << 16
+    __shared__ int nfires[4];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * R;
+    const int nrows = min(R, B - b0);
+    for (int r = 0; r < nrows; ++r)
+        for (int t = tid; t < T; t += 256) a_rows[r * pitch + t] = alphas[(size_t)(b0 + r) * T + t];
+    __syncthreads();
+    if (tid < nrows) {
+        const int b = b0 + tid;
+        const float* row = a_rows + tid * pitch;
+        float* dcr = dc_rows + tid * pitch;
+        float integ = 0.0f;
+        int nfire = 0;
+        for (int t0 = 0; t0 < T; t0 += 16) {
+            float a[16], dcv[16];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-    if (lane == 0 && max_count) atomicMax(max_count, m);
+            for (int k = 0; k < 16; ++k) a[k] = (t0 + k < T) ? row[t0 + k] : 0.0f;
+            uint32_t fb = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                dcv[k] = __fsub_rn(1.0f, integ);
+                integ = __fadd_rn(integ, a[k]);
+                const bool fire = integ >= ((t0 + k < T) ? threshold : __builtin_inff());
+                integ = fire ? __fsub_rn(integ, 1.0f) : integ;
+                fb |= (fire ? 1u : 0u) << k;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (t0 + k < T) dcr[t0 + k] = dcv[k];
+            blk[tid * nblk + (t0 >> 4)] = fb | ((uint32_t)nfire << 16);
+            while (fb) {                                  // fire positions, off the dependent chain
+                const int k = __builtin_ctz(fb);
+                fb &= fb - 1;
+                if (nfire < cap) {
+                    idx_out[(size_t)b * cap + nfire] = t0 + k;
+                    if (mask_out) mask_out[(size_t)b * cap + nfire] = 1;
+                }
+                ++nfire;
+            }
+        }
+        nfires[tid] = nfire;
+        counts[b] = nfire;
+        if (max_count) atomicMax(max_count, nfire);
+    }
+    __syncthreads();
+    for (int r = 0; r < nrows; ++r) {
+        const size_t ob = (size_t)(b0 + r) * T;
+        for (int t = tid; t < T; t += 256) {
+            const uint32_t e = blk[r * nblk + (t >> 4)];
+            const int k = t & 15;
+            const bool fire = (e >> k) & 1u;
+            const int before = (int)(e >> 16) + __popc(e & ((1u << k) - 1u));
+            const float a = a_rows[r * pitch + t];
+            const float c = fire ? dc_rows[r * pitch + t] : a;
+            // one 16-byte record per frame: {cur, rem, (fires before t) << 1 | fired, 0}
+            w_out[ob + t] = (f32x4){c, __fsub_rn(a, c), __int_as_float((before << 1) | (fire ? 1 : 0)), 0.f};
+        }
+        for (int j = nfires[r] + tid; j < cap; j += 256) {
+            idx_out[(size_t)(b0 + r) * cap + j] = -1;
+            if (mask_out) mask_out[(size_t)(b0 + r) * cap + j] = 0;
+        }
+    }
 }
 
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
@@ -100,8 +114,7 @@ template <> __device__ __forceinline__ void st1<__bf16>(__bf16* p, float v) { *p
 // One workgroup per (b, j); thread = VEC consecutive channels; frames in ascending order, mul and add rounded
 // separately like the reference's `frame += cur[:, None] * s_t`.
 template <typename T, int VEC>
-__global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restrict__ s, const float* __restrict__ cur,
-                                                               const float* __restrict__ rem,
+__global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restrict__ s, const f32x4* __restrict__ w,
                                                                const int64_t* __restrict__ idx,
                                                                const int32_t* __restrict__ counts, int Tn, int cap, int d,
                                                                T* __restrict__ out) {
@@ -117,11 +130,11 @@ __global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restr
     const int t_end = (int)idx[(size_t)b * cap + j];
     const int t_prev = (j > 0) ? (int)idx[(size_t)b * cap + j - 1] : -1;
     const T* sb = s + (size_t)b * Tn * d;
-    const float* cb = cur + (size_t)b * Tn;
+    const f32x4* wb = w + (size_t)b * Tn;
     for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC) {
         float acc[VEC];
         if (t_prev >= 0) {
-            const float w = rem[(size_t)b * Tn + t_prev];
+            const float w = wb[t_prev][1];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = __fmul_rn(w, ld1<T>(sb + (size_t)t_prev * d + c + v));
         } else {
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restr
             for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
         }
         for (int t = t_prev + 1; t <= t_end; ++t) {
-            const float w = cb[t];
+            const float w = wb[t][0];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(w, ld1<T>(sb + (size_t)t * d + c + v)));
         }
@@ -142,9 +155,7 @@ __global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restr
 // with g1 = dOut[b, seg_t] (if that row was emitted) and g2 = dOut[b, seg_t + 1] (if t fired and that row exists).
 template <typename T>
 __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ s,
-                                                               const float* __restrict__ cur,
-                                                               const float* __restrict__ rem,
-                                                               const int32_t* __restrict__ seg,
+                                                               const f32x4* __restrict__ w,
                                                                const int32_t* __restrict__ counts, int B, int Tn, int cap,
                                                                int d, T* __restrict__ ds, float* __restrict__ dcur,
                                                                float* __restrict__ drem) {
@@ -153,11 +164,12 @@ __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restr
     if (row >= (int64_t)B * Tn) return;
     const int b = (int)(row / Tn);
     const int cnt = min(counts[b], cap);
-    const int enc = seg[row];
+    const f32x4 wr = w[row];
+    const int enc = __float_as_int(wr[2]);
     const int j = enc >> 1;
     const bool fire = enc & 1;
     const bool has1 = j < cnt, has2 = fire && (j + 1 < cnt);
-    const float c = cur[row], r = rem[row];
+    const float c = wr[0], r = wr[1];
     const T* srow = s + row * d;
     const T* g1 = dout + ((size_t)b * cap + (has1 ? j : 0)) * d;
     const T* g2 = dout + ((size_t)b * cap + (has2 ? j + 1 : 0)) * d;
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restr
 
 // d alpha_u = (fire_u ? drem_u : dcur_u) + sum_{t > u, fire_t} (drem_t - dcur_t): reverse scan, one wave per utterance
 __global__ __launch_bounds__(64) void cif_dalpha_kernel(const float* __restrict__ dcur, const float* __restrict__ drem,
-                                                       const int32_t* __restrict__ seg, int Tn,
+                                                       const f32x4* __restrict__ w, int Tn,
                                                        float* __restrict__ dalphas) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float carry = 0.f;      // sum over firing frames beyond the current chunk
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(64) void cif_dalpha_kernel(const float* __restrict_
         const int t = cidx * 64 + lane;
         const bool ok = t < Tn;
         const size_t o = (size_t)b * Tn + (ok ? t : 0);
-        const bool fire = ok && (seg[o] & 1);
+        const bool fire = ok && (__float_as_int(w[o][2]) & 1);
         const float dc = ok ? dcur[o] : 0.f, dr = ok ? drem[o] : 0.f;
         const float v = fire ? (dr - dc) : 0.f;
         // inclusive suffix sum over the lanes (lane 63 = latest frame of the chunk)
@@ -207,11 +219,12 @@ __global__ __launch_bounds__(64) void cif_dalpha_kernel(const float* __restrict_
 
 }  // namespace star
 
-extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int T, int cap, float* cur, float* rem,
-                                int32_t* seg, int64_t* idx_out, uint8_t* mask_out, int32_t* counts, int32_t* max_count,
+extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int T, int cap, float* weights,
+                                int64_t* idx_out, uint8_t* mask_out, int32_t* counts, int32_t* max_count,
                                 void* stream) {
     using namespace star;
-    STAR_REQUIRE(alphas && cur && rem && seg && idx_out && counts, "star_cif_weights: null pointer");
+    STAR_REQUIRE(alphas && weights && idx_out && counts, "star_cif_weights: null pointer");
+    STAR_REQUIRE((uintptr_t)weights % 16 == 0, "star_cif_weights: weights must be 16-byte aligned");
     STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1, "star_cif_weights: bad shape B=%d T=%d cap=%d", B, T, cap);
     if (max_count) {
         hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int32_t), (hipStream_t)stream);
@@ -220,44 +233,62 @@ extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int
             return STAR_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(cif_weights_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, alphas, threshold, B, T,
-                       cap, cur, rem, seg, idx_out, mask_out, counts, max_count);
+    STAR_REQUIRE(T <= 16384, "star_cif_weights: T=%d exceeds the 16384-frame LDS row limit", T);
+    const int R = cw_rows_per_wg(T);
+    const size_t smem = (size_t)R * cw_row_bytes(T);
+    STAR_REQUIRE(T < 32768, "star_cif_weights: T too large");
+    if (smem > 48 * 1024) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (!attr_done[dev & 63]) {
+            if (hipFuncSetAttribute((const void*)cif_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    140 * 1024) != hipSuccess) {
+                set_error("star_cif_weights: cannot reserve LDS");
+                return STAR_ERR_LAUNCH;
+            }
+            attr_done[dev & 63] = true;
+        }
+    }
+    hipLaunchKernelGGL(cif_weights_kernel, dim3(cdiv(B, R)), dim3(256), smem, (hipStream_t)stream, alphas, threshold, B,
+                       T, cap, R, (f32x4*)weights, idx_out, mask_out, counts, max_count);
     STAR_LAUNCH_CHECK("star_cif_weights");
     return STAR_OK;
 }
 
-extern "C" int star_cif_aggregate_fwd(const void* s, int dtype, const float* cur, const float* rem, const int64_t* idx,
+extern "C" int star_cif_aggregate_fwd(const void* s, int dtype, const float* weights, const int64_t* idx,
                                       const int32_t* counts, int B, int T, int cap, int d, void* out, void* stream) {
     using namespace star;
-    STAR_REQUIRE(s && cur && rem && idx && counts && out, "star_cif_aggregate_fwd: null pointer");
+    STAR_REQUIRE(s && weights && idx && counts && out, "star_cif_aggregate_fwd: null pointer");
+    const f32x4* w4 = (const f32x4*)weights;
     STAR_REQUIRE(B >= 1 && B <= 65535 && T >= 1 && cap >= 1 && d >= 1, "star_cif_aggregate_fwd: bad shape");
     STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_cif_aggregate_fwd: dtype must be bf16 or f32");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(cap, B);
     if (dtype == STAR_DT_BF16) {
         if (d % 8 == 0)
-            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 8>), grid, dim3(128), 0, st, (const __bf16*)s, cur, rem,
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 8>), grid, dim3(128), 0, st, (const __bf16*)s, w4,
                                idx, counts, T, cap, d, (__bf16*)out);
         else
-            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 1>), grid, dim3(128), 0, st, (const __bf16*)s, cur, rem,
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<__bf16, 1>), grid, dim3(128), 0, st, (const __bf16*)s, w4,
                                idx, counts, T, cap, d, (__bf16*)out);
     } else {
         if (d % 4 == 0)
-            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 4>), grid, dim3(128), 0, st, (const float*)s, cur, rem, idx,
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 4>), grid, dim3(128), 0, st, (const float*)s, w4, idx,
                                counts, T, cap, d, (float*)out);
         else
-            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 1>), grid, dim3(128), 0, st, (const float*)s, cur, rem, idx,
+            hipLaunchKernelGGL((cif_aggregate_fwd_kernel<float, 1>), grid, dim3(128), 0, st, (const float*)s, w4, idx,
                                counts, T, cap, d, (float*)out);
     }
     STAR_LAUNCH_CHECK("star_cif_aggregate_fwd");
     return STAR_OK;
 }
 
-extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const float* cur, const float* rem,
-                                      const int32_t* seg, const int32_t* counts, int B, int T, int cap, int d, void* ds,
+extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const float* weights,
+                                      const int32_t* counts, int B, int T, int cap, int d, void* ds,
                                       float* dalphas, float* workspace, void* stream) {
     using namespace star;
-    STAR_REQUIRE(dout && s && cur && rem && seg && counts && ds && dalphas && workspace,
+    STAR_REQUIRE(dout && s && weights && counts && ds && dalphas && workspace,
                  "star_cif_aggregate_bwd: null pointer");
     STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1 && d >= 1, "star_cif_aggregate_bwd: bad shape");
     STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_cif_aggregate_bwd: dtype must be bf16 or f32");
@@ -267,12 +298,12 @@ extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype
     const int64_t rows = (int64_t)B * T;
     if (dtype == STAR_DT_BF16)
         hipLaunchKernelGGL((cif_aggregate_bwd_kernel<__bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const __bf16*)dout,
-                           (const __bf16*)s, cur, rem, seg, counts, B, T, cap, d, (__bf16*)ds, dcur, drem);
+                           (const __bf16*)s, (const f32x4*)weights, counts, B, T, cap, d, (__bf16*)ds, dcur, drem);
     else
         hipLaunchKernelGGL((cif_aggregate_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)dout,
-                           (const float*)s, cur, rem, seg, counts, B, T, cap, d, (float*)ds, dcur, drem);
-    hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(64), 0, st, (const float*)dcur, (const float*)drem, seg, T,
-                       dalphas);
+                           (const float*)s, (const f32x4*)weights, counts, B, T, cap, d, (float*)ds, dcur, drem);
+    hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(64), 0, st, (const float*)dcur, (const float*)drem,
+                       (const f32x4*)weights, T, dalphas);
     STAR_LAUNCH_CHECK("star_cif_aggregate_bwd");
     return STAR_OK;
 }

@@ -327,20 +327,18 @@ class _CifAggregate(torch.autograd.Function):
         dev = s.device
         a = alphas.detach().to(torch.float32).contiguous()
         sc = s.detach().contiguous()
-        cur = torch.empty((B, T), dtype=torch.float32, device=dev)
-        rem = torch.empty((B, T), dtype=torch.float32, device=dev)
-        seg = torch.empty((B, T), dtype=torch.int32, device=dev)
+        wts = torch.empty((B, T, 4), dtype=torch.float32, device=dev)      # {cur, rem, segment/fire bits, 0} per frame
         idx = torch.empty((B, cap), dtype=torch.int64, device=dev)
         mask = torch.empty((B, cap), dtype=torch.uint8, device=dev)
         counts = torch.empty((B,), dtype=torch.int32, device=dev)
         mx = torch.empty((1,), dtype=torch.int32, device=dev)
-        check(lib().star_cif_weights(ptr(a), float(threshold), B, T, cap, ptr(cur), ptr(rem), ptr(seg), ptr(idx),
-                                     ptr(mask), ptr(counts), ptr(mx), stream_ptr()), "star_cif_weights")
+        check(lib().star_cif_weights(ptr(a), float(threshold), B, T, cap, ptr(wts), ptr(idx), ptr(mask), ptr(counts),
+                                     ptr(mx), stream_ptr()), "star_cif_weights")
         out = torch.empty((B, cap, d), dtype=sc.dtype, device=dev)
         dt = DT_BF16 if sc.dtype == torch.bfloat16 else DT_F32
-        check(lib().star_cif_aggregate_fwd(ptr(sc), dt, ptr(cur), ptr(rem), ptr(idx), ptr(counts), B, T, cap, d, ptr(out),
+        check(lib().star_cif_aggregate_fwd(ptr(sc), dt, ptr(wts), ptr(idx), ptr(counts), B, T, cap, d, ptr(out),
                                            stream_ptr()), "star_cif_aggregate_fwd")
-        ctx.save_for_backward(sc, cur, rem, seg, counts)
+        ctx.save_for_backward(sc, wts, counts)
         ctx.cap = cap
         ctx.a_dtype = alphas.dtype
         ctx.mark_non_differentiable(idx, mask, counts, mx)
@@ -350,15 +348,15 @@ class _CifAggregate(torch.autograd.Function):
     def backward(ctx, g, *unused):
         if g is None:
             return None, None, None, None
-        sc, cur, rem, seg, counts = ctx.saved_tensors
+        sc, wts, counts = ctx.saved_tensors
         B, T, d = sc.shape
         gc = g.to(sc.dtype).contiguous()
         ds = torch.empty_like(sc)
         da = torch.empty((B, T), dtype=torch.float32, device=sc.device)
         ws = torch.empty((2 * B * T,), dtype=torch.float32, device=sc.device)
         dt = DT_BF16 if sc.dtype == torch.bfloat16 else DT_F32
-        check(lib().star_cif_aggregate_bwd(ptr(gc), ptr(sc), dt, ptr(cur), ptr(rem), ptr(seg), ptr(counts), B, T, ctx.cap,
-                                           d, ptr(ds), ptr(da), ptr(ws), stream_ptr()), "star_cif_aggregate_bwd")
+        check(lib().star_cif_aggregate_bwd(ptr(gc), ptr(sc), dt, ptr(wts), ptr(counts), B, T, ctx.cap, d, ptr(ds),
+                                           ptr(da), ptr(ws), stream_ptr()), "star_cif_aggregate_bwd")
         return da.to(ctx.a_dtype), ds, None, None
 
 

@@ -84,3 +84,13 @@ for w in a.what:
         tl = torch.full((B,), int(0.075 * T) + 2, dtype=torch.int32, device=dev)
         timeit("cif_resize", lambda: ops.cif_resize(al, tl))
         timeit("cif_fire_scan", lambda: ops.cif_fire_scan(al, lengths=ln, cap=int(0.075 * T) + 4))
+    elif w == "cifagg":
+        al = (torch.rand(B, T, device=dev) * (2.0 * L / T)).requires_grad_()       # ~L fires per utterance
+        s = torch.randn(B, T, d, device=dev).bfloat16().requires_grad_()
+        cap = 2 * L + 8
+        with torch.no_grad():
+            timeit("cif_aggregate fwd", lambda: ops.cif_aggregate(al, s, cap=cap), bytes_=(B * T + B * L) * d * 2.0)
+        out = ops.cif_aggregate(al, s, cap=cap)[0]
+        go = torch.randn_like(out)
+        timeit("cif_aggregate bwd", lambda: torch.autograd.grad(out, (al, s), go, retain_graph=True),
+               bytes_=2.0 * B * T * d * 2.0)
