@@ -243,7 +243,9 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: non-streaming nugget compression, wav2vec2-large states",
+            "config": {"workload": ("configs[1]: non-streaming nugget compression, wav2vec2-large states"
+                                    if (B, T, d, h, L, nl, rate) == (32, 1500, 1024, 8, 128, 4, 4)
+                                    else "custom shape (parity-case configuration, not the headline workload)"),
                        "batch_per_gpu": B, "global_batch": B * world, "frames": T, "d": d, "rate": rate,
                        "K": int(inp.key_len_dev(rate)[1]), "layers": nl, "heads": h, "tgt_len": L,
                        "parallelism": f"dp{world}", "hip_graph": graph is not None,
