@@ -41,6 +41,8 @@ struct alignas(sizeof(T) * N) Pack {
 
 // T_ELEM: __bf16 or float; rows are d elements, moved VEC elements per lane per step
 // (VEC = 4 when d % 4 == 0, else 1 -- the scalar score gather of w2v_simul.py:427 has d = 1).
+constexpr int GB_MAXV = 4;     // row vectors per lane kept in registers by the duplicate path (d <= 1024 at VEC 4)
+
 template <typename T_ELEM, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __restrict__ ddst,
                                                               const int64_t* __restrict__ idx,
@@ -81,8 +83,68 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
         } else if (c == 1) {
             const vec4* in = (const vec4*)(ddst + ((size_t)b * K + first_j[r]) * d);
             for (int v = lane; v < nvec; v += 64) out[v] = in[v];
+        } else if (nvec <= 64 * GB_MAXV) {
+            // duplicates (only pad slots produce them in this pipeline): fp32 sum in ascending j.  The wave finds the
+            // matching slots 64 at a time with a ballot and keeps the whole row in registers, so idx is read once.
+            float acc[GB_MAXV][VEC];
+#pragma unroll
+            for (int i = 0; i < GB_MAXV; ++i)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[i][q] = 0.f;
+            const int jf = first_j[r];
+            for (int j0 = jf & ~63; j0 < K; j0 += 64) {
+                const int j = j0 + lane;
+                bool m = false;
+                if (j < K && j >= jf) {
+                    int64_t tj = irow[j];
+                    if (tj < 0) tj += T;
+                    m = (tj == t);
+                }
+                unsigned long long bal = __ballot(m);
+                // four matching rows per round: all their loads are issued before the first add (one wave owns the
+                // row, so the loads of consecutive matches must overlap or the round trips add up)
+                while (bal) {
+                    int ks[4];
+                    const int kfirst = __builtin_ctzll(bal);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ks[u] = bal ? __builtin_ctzll(bal) : -1;
+                        bal &= bal - 1;          // (0 & anything stays 0)
+                    }
+                    // every load is unconditional (rows / vectors that do not exist re-read a valid address and are
+                    // dropped at the add): a branch around a load makes the compiler drain vmcnt(0) per element
+                    vec4 x[4][GB_MAXV];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ku = ks[u] >= 0 ? ks[u] : kfirst;
+                        const vec4* in = (const vec4*)(ddst + ((size_t)b * K + j0 + ku) * d);
+#pragma unroll
+                        for (int i = 0; i < GB_MAXV; ++i) x[u][i] = in[min(lane + 64 * i, nvec - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int i = 0; i < GB_MAXV; ++i)
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) {
+                                const float xv = (float)x[u][i].v[q];
+                                acc[i][q] += (ks[u] >= 0) ? xv : 0.0f;      // a missing row adds +0
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GB_MAXV; ++i) {
+                const int v = lane + 64 * i;
+                if (v < nvec) {
+                    vec4 o;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) o.v[q] = (T_ELEM)acc[i][q];
+                    out[v] = o;
+                }
+            }
         } else {
-            // duplicates (only pad slots produce them in this pipeline): ordered fp32 sum
+            // very wide rows: one vector at a time
             for (int v = lane; v < nvec; v += 64) {
                 float acc[VEC];
 #pragma unroll
