@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void cif_weights_kernel(const float* __restric
     }
 }
 
+template <typename T, int N> struct __attribute__((aligned(sizeof(T) * N))) Pack { T v[N]; };
+
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<__bf16>(const __bf16* p) { return (float)*p; }
@@ -153,12 +155,14 @@ __global__ __launch_bounds__(128) void cif_aggregate_fwd_kernel(const T* __restr
 
 // One wave per frame (b, t):  dS_t = cur_t * g1 + rem_t * g2,  dcur_t = <s_t, g1>,  drem_t = <s_t, g2>
 // with g1 = dOut[b, seg_t] (if that row was emitted) and g2 = dOut[b, seg_t + 1] (if t fired and that row exists).
-template <typename T>
+// Loads are unconditional vector loads (rows that do not exist re-read row 0 and get weight 0).
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ s,
                                                                const f32x4* __restrict__ w,
                                                                const int32_t* __restrict__ counts, int B, int Tn, int cap,
                                                                int d, T* __restrict__ ds, float* __restrict__ dcur,
                                                                float* __restrict__ drem) {
+    typedef Pack<T, VEC> vec;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * Tn) return;
@@ -169,19 +173,25 @@ __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restr
     const int j = enc >> 1;
     const bool fire = enc & 1;
     const bool has1 = j < cnt, has2 = fire && (j + 1 < cnt);
-    const float c = wr[0], r = wr[1];
-    const T* srow = s + row * d;
-    const T* g1 = dout + ((size_t)b * cap + (has1 ? j : 0)) * d;
-    const T* g2 = dout + ((size_t)b * cap + (has2 ? j + 1 : 0)) * d;
-    T* drow = ds + row * d;
+    const float c = has1 ? wr[0] : 0.f, r = has2 ? wr[1] : 0.f;
+    const vec* srow = (const vec*)(s + row * d);
+    const vec* g1 = (const vec*)(dout + ((size_t)b * cap + (has1 ? j : 0)) * d);
+    const vec* g2 = (const vec*)(dout + ((size_t)b * cap + (has2 ? j + 1 : 0)) * d);
+    vec* drow = (vec*)(ds + row * d);
     float a1 = 0.f, a2 = 0.f;
-    for (int ch = lane; ch < d; ch += 64) {
-        const float sv = ld1<T>(srow + ch);
-        const float v1 = has1 ? ld1<T>(g1 + ch) : 0.f;
-        const float v2 = has2 ? ld1<T>(g2 + ch) : 0.f;
-        a1 += sv * v1;
-        a2 += sv * v2;
-        st1<T>(drow + ch, c * v1 + r * v2);
+    const int nvec = d / VEC;
+    for (int v = lane; v < nvec; v += 64) {
+        const vec sv = srow[v], v1 = g1[v], v2 = g2[v];
+        vec o;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float sf = (float)sv.v[q];
+            const float f1 = has1 ? (float)v1.v[q] : 0.f, f2 = has2 ? (float)v2.v[q] : 0.f;   // selects, not branches
+            a1 += sf * f1;
+            a2 += sf * f2;
+            o.v[q] = (T)(c * f1 + r * f2);
+        }
+        drow[v] = o;
     }
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
@@ -296,12 +306,18 @@ extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype
     float* dcur = workspace;
     float* drem = workspace + (size_t)B * T;
     const int64_t rows = (int64_t)B * T;
-    if (dtype == STAR_DT_BF16)
-        hipLaunchKernelGGL((cif_aggregate_bwd_kernel<__bf16>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const __bf16*)dout,
-                           (const __bf16*)s, (const f32x4*)weights, counts, B, T, cap, d, (__bf16*)ds, dcur, drem);
-    else
-        hipLaunchKernelGGL((cif_aggregate_bwd_kernel<float>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)dout,
-                           (const float*)s, (const f32x4*)weights, counts, B, T, cap, d, (float*)ds, dcur, drem);
+    const bool al16 = ((uintptr_t)dout % 16 == 0) && ((uintptr_t)s % 16 == 0) && ((uintptr_t)ds % 16 == 0);
+#define STAR_CIF_BWD(TT, VV)                                                                                          \
+    hipLaunchKernelGGL((cif_aggregate_bwd_kernel<TT, VV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)dout,    \
+                       (const TT*)s, (const f32x4*)weights, counts, B, T, cap, d, (TT*)ds, dcur, drem)
+    if (dtype == STAR_DT_BF16) {
+        if (d % 8 == 0 && al16) STAR_CIF_BWD(__bf16, 8);
+        else STAR_CIF_BWD(__bf16, 1);
+    } else {
+        if (d % 4 == 0 && al16) STAR_CIF_BWD(float, 4);
+        else STAR_CIF_BWD(float, 1);
+    }
+#undef STAR_CIF_BWD
     hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(64), 0, st, (const float*)dcur, (const float*)drem,
                        (const f32x4*)weights, T, dalphas);
     STAR_LAUNCH_CHECK("star_cif_aggregate_bwd");
