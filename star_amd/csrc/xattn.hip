@@ -54,8 +54,9 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
 
 // Register-staged tile copy, split in two halves so that the global loads of tile t+1 are in flight
 // while tile t is being consumed (issue early / write late):
-//   tile_load : rows [r0, r0+ROWS) x HD of a strided bf16 matrix -> registers (rows >= limit read as zero;
-//               addresses are clamped so every load is unconditional and the compiler batches them)
+//   tile_load : rows [r0, r0+ROWS) x HD of a strided bf16 matrix -> registers.  Rows >= limit re-read row
+//               limit-1 (clamped address, finite data): every consumer masks them (their P / dS are exact zeros),
+//               and a "load or zero" select would make the compiler branch around each load
 //   tile_store: registers -> LDS tile with the given pitch
 // NTH = threads of the workgroup that take part.
 template <int HD, int ROWS, int NTH = XA_THREADS>
@@ -75,9 +76,7 @@ __device__ __forceinline__ void tile_load(TileRegs<HD, ROWS, NTH>& t, const __bf
         const int c = threadIdx.x + i * NTH;
         const int row = c / TR::CPR, ch = c % TR::CPR;
         const int rr = min(r0 + row, limit - 1);
-        u32x4 v = *(const u32x4*)(g + (int64_t)rr * sr + ch * 8);
-        const bool ok = (r0 + row < limit);
-        t.v[i] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+        t.v[i] = *(const u32x4*)(g + (int64_t)rr * sr + ch * 8);
     }
 }
 
@@ -156,11 +155,16 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
         for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
     float m_run = NEG_SENTINEL, l_run = 0.f;
 
+    // raw prefetch of the next tile's bias: the value must NOT be touched before the tile is stored to LDS (any
+    // arithmetic on it here makes the compiler drain vmcnt(0), i.e. wait for the K / V prefetch issued just before)
+    const float* bias_row = (bias && s.bias_len > 0) ? bias + (int64_t)b * s.bias_len : nullptr;
     auto load_bias = [&](int kt0) -> float {
         const int key = kt0 + (tid & (KSTEP - 1));
-        float v = 0.f;
-        if (bias && s.bias_len > 0) v = bias[(int64_t)b * s.bias_len + min(key, s.bias_len - 1)];
-        return (key < s.bias_len) ? v * LOG2E : 0.f;
+        return bias_row ? bias_row[min(key, s.bias_len - 1)] : 0.f;
+    };
+    auto bias2 = [&](float raw, int kt0) -> float {
+        const int key = kt0 + (tid & (KSTEP - 1));
+        return (key < s.bias_len) ? raw * LOG2E : 0.f;
     };
     TileRegs<HD, KSTEP, NTH> kreg, vreg;
     float breg = 0.f;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
         __syncthreads();                       // every wave is done reading the previous tiles
         tile_store<HD, KSTEP, NTH>(kreg, k_all, PK);
         tile_store<HD, KSTEP, NTH>(vreg, v_all, PV);
-        if (tid < KSTEP) b_all[tid] = breg;
+        if (tid < KSTEP) b_all[tid] = bias2(breg, kt0);
         __syncthreads();
         if (kt0 + KSTEP < kloop) {             // next tiles' loads fly while these are consumed
             tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, kt0 + KSTEP, s.Kn);
@@ -376,11 +380,16 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[nt][i] = 0.f;
 
+    // raw prefetch of the next tile's bias: the value must NOT be touched before the tile is stored to LDS (any
+    // arithmetic on it here makes the compiler drain vmcnt(0), i.e. wait for the K / V prefetch issued just before)
+    const float* bias_row = (bias && s.bias_len > 0) ? bias + (int64_t)b * s.bias_len : nullptr;
     auto load_bias = [&](int kt0) -> float {
         const int key = kt0 + (tid & (KSTEP - 1));
-        float v = 0.f;
-        if (bias && s.bias_len > 0) v = bias[(int64_t)b * s.bias_len + min(key, s.bias_len - 1)];
-        return (key < s.bias_len) ? v * LOG2E : 0.f;
+        return bias_row ? bias_row[min(key, s.bias_len - 1)] : 0.f;
+    };
+    auto bias2 = [&](float raw, int kt0) -> float {
+        const int key = kt0 + (tid & (KSTEP - 1));
+        return (key < s.bias_len) ? raw * LOG2E : 0.f;
     };
     TileRegs<HD, KSTEP, NTH> kreg, vreg;
     float breg = 0.f;
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
         __syncthreads();
         tile_store<HD, KSTEP, NTH>(kreg, k_all, PK);
         tile_store<HD, KSTEP, NTH>(vreg, v_all, PV);
-        if (tid < KSTEP) b_all[tid] = breg;
+        if (tid < KSTEP) b_all[tid] = bias2(breg, kt0);
         __syncthreads();
         if (kt0 + KSTEP < kloop) {
             tile_load<HD, KSTEP, NTH>(kreg, Kb, s.k_sr, kt0 + KSTEP, s.Kn);
