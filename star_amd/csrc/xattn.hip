@@ -1158,6 +1158,18 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
             }
         }
 
+        // Take over the prefetched fragments BEFORE this group's stores are issued: vmcnt retires in order, so a wait
+        // for these loads placed after the stores (where the compiler puts it on its own) would also wait for
+        // the 33 stores to complete, once per group.
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kfr[ks] = kn[ks];
+            vfr[ks] = vn[ks];
+            asm volatile("" : "+v"(kfr[ks]), "+v"(vfr[ks]));
+        }
+        bias_cur = bias_nxt;
+        asm volatile("" : "+v"(bias_cur));
+
         if (key < s.Kn) {
             __bf16* dkrow = dKb + (int64_t)key * s.k_sr + 4 * g;
             __bf16* dvrow = dVb + (int64_t)key * s.v_sr + 4 * g;
@@ -1176,10 +1188,6 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
         db += __shfl_xor(db, 16, 64);
         db += __shfl_xor(db, 32, 64);
         if (dbias_part && g == 0 && key < s.Kn) dbias_part[((int64_t)b * s.h + h) * s.Kn + key] = db;
-
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { kfr[ks] = kn[ks]; vfr[ks] = vn[ks]; }
-        bias_cur = bias_nxt;
     }
 }
 
