@@ -38,7 +38,8 @@ constexpr int ROW_BYTES = BK * 2;                 // 128-byte LDS rows (8 chunks
 constexpr int HALF_BYTES = 128 * ROW_BYTES;       // half-tile: 128 operand rows x 64 k = 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;         // B-half0 | A-half0 | B-half1 | A-half1
 constexpr int GEMM_LDS = 2 * BUF_BYTES;           // 128 KiB -> one workgroup (2 waves/SIMD) per CU
-constexpr int SCORE_LDS = GEMM_LDS + 4096;        // + row-reduction scratch that outlives the ring (persistent mode)
+constexpr int SCORE_BW_MAXN = 3072;               // b1 / w2 staged in LDS up to this many columns (24 KiB)
+constexpr int SCORE_LDS = GEMM_LDS + 4096 + 2 * SCORE_BW_MAXN * 4;   // + row-reduction scratch and b1 / w2 behind the ring
 // half-tile kinds in staging (= consumption) order.  A-half h holds, for both wave rows, the 64 rows of
 // accumulator quadrant row h (tile rows wr*128 + h*64 ..); B-half h the 32 columns wc*64 + h*32 .. of all four
 // wave columns.
@@ -153,6 +154,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     // ---- per-lane staging sources: wave w stages pieces 2w, 2w+1 (8 rows x 128 B each) of every half-tile;
     // lane l -> half-tile row piece*8 + (l >> 3), LDS position l & 7, source chunk (l & 7) ^ swz8(row).
     auto make_src = [&](const __bf16* (&out)[4][2], int mm0, int nn0) {
+        // A rows first: with a row gather the four index loads are issued together (a load inside the pointer
+        // loop would be waited for one at a time)
+        int64_t arow[2][2];
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hr = (wid * 2 + i) * 8 + (lane >> 3);
+                int am = mm0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
+                if (am >= p.M) am = p.M - 1;
+                arow[hsel][i] = am;
+            }
+        if (p.a_rows) {
+            int32_t g[2][2];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) g[hsel][i] = p.a_rows[arow[hsel][i] < p.a_rows_n ? arow[hsel][i] : 0];
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) arow[hsel][i] = g[hsel][i];
+        }
 #pragma unroll
         for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
@@ -161,11 +185,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                 const int chunk = (lane & 7) ^ swz8(hr);
                 const int hsel = kind >> 1;
                 if (kind & 1) {   // A operand
-                    int am = mm0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
-                    if (am >= p.M) am = p.M - 1;
-                    int64_t arow = am;
-                    if (p.a_rows) arow = (am < p.a_rows_n) ? p.a_rows[am] : p.a_rows[0];
-                    out[kind][i] = p.A + arow * p.lda + (int64_t)kc0 * BK + chunk * 8;
+                    out[kind][i] = p.A + arow[hsel][i] * p.lda + (int64_t)kc0 * BK + chunk * 8;
                 } else {          // B operand
                     int bn = nn0 + (hr >> 5) * 64 + hsel * 32 + (hr & 31);
                     if (bn >= p.N) bn = p.N - 1;
@@ -264,6 +284,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+    // EPI_SCORE: b1 / w2 of all columns into LDS once, so that the epilogues (which run while the next tile's DMA
+    // is in flight) touch no register-destination global load -- hipcc would drain vmcnt(0) at its first use
+    float* bw_lds = (float*)(lds + GEMM_LDS + 4096);
+    const bool bw_staged = PERSIST && (nbn * BN <= SCORE_BW_MAXN);
+    if constexpr (PERSIST) {
+        if (bw_staged) {
+            for (int n = tid; n < nbn * BN; n += GEMM_THREADS) {
+                bw_lds[n] = n < p.N ? p.b1[n] : 0.f;
+                bw_lds[SCORE_BW_MAXN + n] = n < p.N ? p.w2[n] : 0.f;
+            }
+            __syncthreads();
+        }
+    }
+
   for (;;) {      // output tiles of this workgroup (one iteration unless PERSIST)
     int nm_tile = 0, nn_tile = 0, nsplit = 0;
     if constexpr (PERSIST) {
@@ -320,8 +354,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = n0 + wcol0 + tn * 16 + ccol;
-            bb[tn] = n < p.N ? p.b1[n] : 0.f;
-            ww[tn] = n < p.N ? p.w2[n] : 0.f;
+            if (bw_staged) {
+                bb[tn] = bw_lds[n];
+                ww[tn] = bw_lds[SCORE_BW_MAXN + n];
+            } else {
+                bb[tn] = n < p.N ? p.b1[n] : 0.f;
+                ww[tn] = n < p.N ? p.w2[n] : 0.f;
+            }
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
