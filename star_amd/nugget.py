@@ -197,6 +197,28 @@ class NuggetCrossAttention(nn.Module):
         self.q_attn = Conv1D(hidden_size, hidden_size)
         self.c_proj = Conv1D(hidden_size, hidden_size)
         self.resid_dropout = nn.Dropout(resid_pdrop)
+        self._kv_cache = None        # (tag, key, value) of the last encoder memory seen under no_grad / eval
+
+    def clear_kv_cache(self):
+        self._kv_cache = None
+
+    def _encoder_kv(self, encoder_hidden_states):
+        """K/V of the encoder memory.  During generation the reference recomputes c_attn(encoder_hidden_states) for
+        every decoded token (my_transformer.py:724-733,1079-1099) although the memory does not change; here, in eval
+        mode under no_grad, the projected heads are kept while the memory tensor and the projection weights are the
+        very same objects at the same version."""
+        cacheable = (not self.training) and (not torch.is_grad_enabled())
+        tag = None
+        if cacheable:
+            e, w, bb = encoder_hidden_states, self.c_attn.weight, self.c_attn.bias
+            tag = (e.data_ptr(), tuple(e.shape), e.dtype, e._version, w.data_ptr(), w._version, bb.data_ptr(), bb._version)
+            if self._kv_cache is not None and self._kv_cache[0] == tag:
+                return self._kv_cache[1], self._kv_cache[2]
+        key, value = self.c_attn(encoder_hidden_states).split(self.split_size, dim=2)
+        key, value = self._split_heads(key), self._split_heads(value)
+        # the memory tensor itself is kept alive with the entry, so its address cannot be handed to another tensor
+        self._kv_cache = (tag, key, value, encoder_hidden_states) if cacheable else None
+        return key, value
 
     def _split_heads(self, t):
         return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).permute(0, 2, 1, 3)
@@ -213,8 +235,7 @@ class NuggetCrossAttention(nn.Module):
         if encoder_hidden_states is None:
             raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
         query = self._split_heads(self.q_attn(hidden_states))
-        key, value = self.c_attn(encoder_hidden_states).split(self.split_size, dim=2)
-        key, value = self._split_heads(key), self._split_heads(value)
+        key, value = self._encoder_kv(encoder_hidden_states)
         if layer_past is not None:
             past_key, past_value = layer_past
             key = torch.cat((past_key, key), dim=-2)

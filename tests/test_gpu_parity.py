@@ -436,6 +436,46 @@ def test_dropin_signatures(ops):
     np.testing.assert_allclose(p.cpu().numpy(), x["p"], rtol=5e-2, atol=5e-3)
 
 
+def test_cross_attention_kv_cache(ops):
+    """Generation keeps the projected encoder K/V: the reference recomputes c_attn(memory) for every
+    token (my_transformer.py:724-733); the cached path must give the same output and project the memory once."""
+    from star_amd.nugget import NuggetCrossAttention
+    torch.manual_seed(3)
+    d, h, B, K = 512, 8, 3, 40
+    m = NuggetCrossAttention(d, h).to(DEV, torch.bfloat16)
+    calls = []
+    m.c_attn.register_forward_hook(lambda *a: calls.append(1))
+    enc = torch.randn(B, K, d, device=DEV, dtype=torch.bfloat16)
+    sc = torch.randn(B, K, device=DEV)
+    steps = [torch.randn(B, 1, d, device=DEV, dtype=torch.bfloat16) for _ in range(3)]
+
+    m.train()
+    ref = [m(x, encoder_hidden_states=enc, scorer_logits=sc)[0].detach() for x in steps]
+    assert len(calls) == 3 and m._kv_cache is None          # training never caches
+
+    m.eval()
+    calls.clear()
+    with torch.no_grad():
+        got = [m(x, encoder_hidden_states=enc, scorer_logits=sc)[0] for x in steps]
+        assert len(calls) == 1
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        enc.mul_(0.5)                                         # in-place change of the memory invalidates the entry
+        o1 = m(steps[0], encoder_hidden_states=enc, scorer_logits=sc)[0]
+        assert len(calls) == 2 and not torch.equal(o1, ref[0])
+        enc2 = enc.clone()                                    # another tensor with equal contents: recomputed, equal
+        o2 = m(steps[0], encoder_hidden_states=enc2, scorer_logits=sc)[0]
+        assert len(calls) == 3 and torch.equal(o1, o2)
+        m.c_attn.weight.mul_(1.5)                             # weights changed (e.g. a checkpoint load)
+        m(steps[0], encoder_hidden_states=enc2, scorer_logits=sc)
+        assert len(calls) == 4
+        m.clear_kv_cache()
+        m(steps[0], encoder_hidden_states=enc2, scorer_logits=sc)
+        assert len(calls) == 5
+    m(steps[0], encoder_hidden_states=enc2, scorer_logits=sc)  # eval but grad enabled: no cache
+    assert len(calls) == 6 and m._kv_cache is None
+
+
 # ------------------------------------------------------------------------------------------------ whole step
 def test_nugget_step_asr_vs_oracle(ops):
     from star_amd.nugget import NuggetScorer
