@@ -1191,6 +1191,352 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
     }
 }
 
+// Fused short-target backward (L <= 128, HD = 64 or 128, B*h large enough to fill the chip on its own): dQ, dK, dV
+// and the bias-gradient partials of one (batch, head) from ONE pass over K / V.  The two products want opposite
+// ownerships (dK/dV: a wave owns keys and sees every query; dQ: a wave owns queries and sees every key), so the keys
+// are walked in rounds of 128 = one 16-key group per wave:
+//   phase B  the dkv_small walk for the wave's group (S, dP, dS, dK^T, dV^T); on the way the wave parks its K
+//            fragment and its bf16 dS block [16 keys][128 queries] in LDS
+//   barrier
+//   phase C  wave w now owns queries 16w..16w+15: dQ^T[hd][q] += K^T[hd][key] dS^T[key][q] over the round's keys,
+//            both operands by transposed LDS reads (the same key permutation on both sides)
+//   dK / dV stores of the round, barrier (LDS is re-used by the next round)
+// delta = rowsum(dO * O) is formed while the Q / dO block is staged.  Compared with the dQ + dK/dV pair this reads
+// K, V, Q, dO once instead of twice and recomputes S / dP once instead of twice.
+template <int HD>
+struct BwdFused {
+    static constexpr int QROWS = 128, KROWS = 128, WAVES = 8;
+    static constexpr int ROWB = HD * 2;
+    static constexpr int DSB = QROWS * 2;                       // one dS row: 128 queries of one key
+    static constexpr int K_OFF = 2 * QROWS * ROWB;
+    static constexpr int DS_OFF = K_OFF + KROWS * ROWB;
+    static constexpr int LSE_OFF = DS_OFF + KROWS * DSB;
+    static constexpr int BYTES = LSE_OFF + 2 * QROWS * 4;
+};
+
+__device__ __forceinline__ void xa_lds_barrier() {
+    // LDS traffic of this wave done, then the workgroup barrier; global stores / prefetches stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
+    const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
+    const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
+    const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dQ,
+    __bf16* __restrict__ dK, __bf16* __restrict__ dV, float* __restrict__ dbias_part, int dbg) {
+    using C = DkvSmall<HD>;
+    using F = BwdFused<HD>;
+    constexpr int NTH = 512, QROWS = F::QROWS, ROWB = F::ROWB, DSB = F::DSB;
+    constexpr int KS = HD / 32;       // k-steps of a 16x16x32 MFMA over the head dim
+    constexpr int NT = HD / 16;       // 16-wide head-dim tiles of dK^T / dV^T / dQ^T
+    constexpr int CPR = HD / 8;       // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* q_lds = smem;                          // [128 queries][ROWB] swizzled
+    uint8_t* g_lds = q_lds + QROWS * ROWB;          // [128 queries][ROWB] swizzled
+    uint8_t* k_lds = smem + F::K_OFF;               // [128 keys of the round][ROWB] swizzled
+    uint8_t* ds_lds = smem + F::DS_OFF;             // [128 keys of the round][128 queries] bf16, swizzled
+    float* lse_lds = (float*)(smem + F::LSE_OFF);   // [128] (log2 domain)
+    float* del_lds = lse_lds + QROWS;               // [128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+
+    const __bf16* Qb = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh;
+    const __bf16* Ob = O + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
+    const __bf16* dOb = dO + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh;
+    const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+    const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+    __bf16* dKb = dK + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+    __bf16* dVb = dV + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+
+    int kend = s.Kn;
+    if (key_len) kend = min(kend, key_len[b]);
+    const float scale2 = s.scale * LOG2E;
+    const int ngroups = (s.Kn + 15) >> 4;
+    const int nrounds = (s.Kn + F::KROWS - 1) / F::KROWS;
+
+    // first group's K / V fragments: issued before the Q / dO staging so that both are in flight together
+    bf16x8 kfr[KS], vfr[KS];
+    float bias_cur = 0.f;
+    {
+        const int key = min(wid * 16 + r16, s.Kn - 1);
+        const __bf16* krow = Kb + (int64_t)key * s.k_sr + g * 8;
+        const __bf16* vrow = Vb + (int64_t)key * s.v_sr + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kfr[ks] = *(const bf16x8*)(krow + ks * 32);
+            vfr[ks] = *(const bf16x8*)(vrow + ks * 32);
+        }
+        if (bias && key < s.bias_len) bias_cur = bias[(int64_t)b * s.bias_len + key];
+    }
+    {
+        TileRegs<HD, QROWS, NTH> qreg, greg, oreg;
+        tile_load<HD, QROWS, NTH>(qreg, Qb, s.q_sr, 0, s.L);
+        tile_load<HD, QROWS, NTH>(greg, dOb, s.o_sr, 0, s.L);
+        tile_load<HD, QROWS, NTH>(oreg, Ob, s.o_sr, 0, s.L);
+        float lreg = 0.f;
+        if (tid < QROWS) lreg = lse[((int64_t)b * s.h + h) * s.L + min(tid, s.L - 1)] * LOG2E;
+#pragma unroll
+        for (int i = 0; i < TileRegs<HD, QROWS, NTH>::N; ++i) {
+            const int c = tid + i * NTH;
+            const int row = c / CPR, ch = c % CPR;
+            const int off = row * ROWB + ((ch ^ C::swz(row & 15)) << 4);
+            *(u32x4*)(q_lds + off) = qreg.v[i];
+            *(u32x4*)(g_lds + off) = greg.v[i];
+            // delta[row] = sum over the row of dO * O: the CPR lanes that hold one row are neighbours
+            const bf16x8 gv = __builtin_bit_cast(bf16x8, greg.v[i]);
+            const bf16x8 ov = __builtin_bit_cast(bf16x8, oreg.v[i]);
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += (float)gv[j] * (float)ov[j];
+#pragma unroll
+            for (int m = 1; m < CPR; m <<= 1) d += __shfl_xor(d, m, 64);
+            if (ch == 0) del_lds[row] = d;
+        }
+        if (tid < QROWS) lse_lds[tid] = lreg;
+    }
+    __syncthreads();
+
+    const int nslices = (s.L + 31) >> 5;
+    const int sw_row = C::swz(r16);                               // row reads: row = 16t + r16
+    const int tr_row = 4 * g + (r16 >> 2);                        // transposed reads: row within a 32-row slice
+    const int sw_tr = C::swz(tr_row);
+    const int sw_ds_row = (r16 & 7) << 1;                         // dS tile: 256-byte rows
+    const int sw_ds_tr = (tr_row & 7) << 1;
+    const int qw0 = wid * 16;                                     // phase C: first query of this wave
+    const bool wave_has_q = qw0 < s.L;
+
+    f32x4 dq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        const int grp = rnd * F::WAVES + wid;
+        const int key = grp * 16 + r16;
+        const bool key_ok = key < kend;
+        const float my_bias2 = bias_cur * LOG2E;
+        const int qmin = key_ok ? (s.ilk_diag >= 0 ? key - s.ilk_diag : -(1 << 30)) : 0x7fffffff;
+        // park this group's K rows for phase C (rows past Kn hold a clamped, finite row: their dS is zero)
+        uint8_t* krow_lds = k_lds + (16 * wid + r16) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) *(bf16x8*)(krow_lds + (((4 * ks + g) ^ sw_row) << 4)) = kfr[ks];
+        uint8_t* ds_row = ds_lds + (16 * wid + r16) * DSB + 8 * (g & 1);
+
+        f32x4 dk[NT], dv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dk[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        float db = 0.f;
+        const bool grp_live = grp * 16 < kend;
+
+#pragma unroll 1
+        for (int sl = 0; sl < nslices; ++sl) {
+            const int q0 = sl * 32;
+            const int dsc0 = ((4 * sl + (g >> 1)) ^ sw_ds_row) << 4, dsc1 = ((4 * sl + 2 + (g >> 1)) ^ sw_ds_row) << 4;
+            if ((dbg & 4) || !grp_live || (s.ilk_diag >= 0 && grp * 16 > q0 + 31 + s.ilk_diag)) {       // wave-uniform
+                *(uint2*)(ds_row + dsc0) = make_uint2(0u, 0u);
+                *(uint2*)(ds_row + dsc1) = make_uint2(0u, 0u);
+                continue;
+            }
+            // S[q][key], dP[q][key] and the softmax arithmetic for two 16-query tiles, one after the other (the
+            // HD = 128 kernel has no room for the fragments of both at once next to the dK / dV / dQ accumulators).
+            // The wave's own K rows come back from the LDS copy made for phase C (program order: no barrier needed),
+            // which frees their registers for the whole slice loop.
+            bf16x8 kb[KS];
+            if constexpr (HD == 128) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kb[ks] = lds_row8(krow_lds + (((4 * ks + g) ^ sw_row) << 4));
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kb[ks] = kfr[ks];
+            }
+            // transposed dO / Q fragments in four steps of TPS head-dim tiles: the first step is in flight during the
+            // softmax arithmetic, every further one behind the MFMAs of the step before it
+            constexpr int TPS = NT / 4;
+            const int trbase = (q0 + tr_row) * ROWB + 8 * (lane & 1);
+            bf16x8 gt[TPS], qt[TPS];
+            bf16x8 pf, df;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x8 qa[KS], ga[KS];
+                const int rowoff = (q0 + 16 * t + r16) * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = rowoff + (((4 * ks + g) ^ sw_row) << 4);
+                    qa[ks] = lds_row8(q_lds + off);
+                    ga[ks] = lds_row8(g_lds + off);
+                }
+                const f32x4 ll = *(const f32x4*)(lse_lds + q0 + 16 * t + 4 * g);
+                const f32x4 dd = *(const f32x4*)(del_lds + q0 + 16 * t + 4 * g);
+                f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, pacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kb[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[ks], vfr[ks], pacc, 0, 0, 0);
+                }
+                if (t == 1) {
+#pragma unroll
+                    for (int nt = 0; nt < TPS; ++nt) {
+                        const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                        gt[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
+                        qt[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
+                    }
+                }
+                // visibility of (query, key): key valid, query < L, key <= query + diag  <=>  qmin <= query < L
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qq = q0 + 16 * t + 4 * g + j;
+                    float p = __builtin_amdgcn_exp2f(sacc[j] * scale2 + my_bias2 - ll[j]);
+                    p = (qq >= qmin && qq < s.L) ? p : 0.f;
+                    const float ds = p * (pacc[j] - dd[j]);
+                    db += ds;
+                    pf[4 * t + j] = (__bf16)p;
+                    df[4 * t + j] = (__bf16)ds;
+                }
+            }
+            // dS of (this key, queries q0+16t+4g .. +3) for phase C
+            {
+                const u32x4 dfw = __builtin_bit_cast(u32x4, df);
+                *(uint2*)(ds_row + dsc0) = make_uint2(dfw[0], dfw[1]);
+                *(uint2*)(ds_row + dsc1) = make_uint2(dfw[2], dfw[3]);
+            }
+            if constexpr (HD == 128) __builtin_amdgcn_sched_barrier(0);     // keeps the later fragment reads below
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                bf16x8 gt2[TPS], qt2[TPS];
+                if (st < 3) {
+#pragma unroll
+                    for (int nt = 0; nt < TPS; ++nt) {
+                        const int off = trbase + (((2 * (nt + (st + 1) * TPS) + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                        gt2[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
+                        qt2[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < TPS; ++nt) {
+                    dv[nt + st * TPS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt[nt], pf, dv[nt + st * TPS], 0, 0, 0);
+                    dk[nt + st * TPS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[nt], df, dk[nt + st * TPS], 0, 0, 0);
+                }
+                if (st < 3) {
+#pragma unroll
+                    for (int nt = 0; nt < TPS; ++nt) { gt[nt] = gt2[nt]; qt[nt] = qt2[nt]; }
+                }
+            }
+        }
+
+        // The next round's K / V fragments go straight into the (now dead) fragment registers: the HD = 128 kernel has
+        // no room for a second set next to the dQ accumulators.  They are in flight across the barrier and phase C and
+        // are waited for BEFORE this round's stores are issued (vmcnt retires in order).
+        {
+            const int ng = grp + F::WAVES;
+            const int nkey = (dbg & 8) ? r16 : min((ng < ngroups ? ng : grp) * 16 + r16, s.Kn - 1);
+            const __bf16* krow = Kb + (int64_t)nkey * s.k_sr + g * 8;
+            const __bf16* vrow = Vb + (int64_t)nkey * s.v_sr + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kfr[ks] = *(const bf16x8*)(krow + ks * 32);
+                vfr[ks] = *(const bf16x8*)(vrow + ks * 32);
+            }
+            bias_cur = 0.f;
+            if (bias && nkey < s.bias_len) bias_cur = bias[(int64_t)b * s.bias_len + nkey];
+        }
+
+        xa_lds_barrier();          // K rows and dS of the whole round are in LDS
+
+        // phase C: this wave's 16 queries against the round's keys
+        if (wave_has_q && !(dbg & 2)) {
+#pragma unroll 1
+            for (int kk = 0; kk < F::KROWS / 32; ++kk) {
+                const int k0 = rnd * F::KROWS + 32 * kk;
+                if (k0 >= kend) break;                                                   // wave-uniform
+                if (s.ilk_diag >= 0 && k0 > qw0 + 15 + s.ilk_diag) break;                // invisible to all 16 queries
+                const int trb = (32 * kk + tr_row) * ROWB + 8 * (lane & 1);
+                bf16x8 kt[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int off = trb + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                    kt[nt] = lds_tr8(k_lds + off, k_lds + off + 16 * ROWB);
+                }
+                const int dso = (32 * kk + tr_row) * DSB + 8 * (lane & 1) + (((2 * wid + ((lane & 3) >> 1)) ^ sw_ds_tr) << 4);
+                const bf16x8 dst = lds_tr8(ds_lds + dso, ds_lds + dso + 16 * DSB);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[nt], dst, dq[nt], 0, 0, 0);
+            }
+        }
+
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kfr[ks]), "+v"(vfr[ks]));
+        asm volatile("" : "+v"(bias_cur));
+
+        db += __shfl_xor(db, 16, 64);
+        db += __shfl_xor(db, 32, 64);
+        if (dbias_part && g == 0 && key < s.Kn) dbias_part[((int64_t)b * s.h + h) * s.Kn + key] = db;
+
+        xa_lds_barrier();      // phase C reads done: the round's LDS rows are free again
+
+        // dK / dV of the round leave through the wave's own 16 rows of the K and dS tiles (free until the next
+        // round's writes, which follow in program order): accumulator layout -> row-major, so that every store
+        // instruction writes whole 16-byte-per-lane rows instead of 32-byte fragments of 16 rows
+        if (!(dbg & 1)) {
+            uint8_t* tk = k_lds + 16 * wid * ROWB;
+            uint8_t* tv = ds_lds + 16 * wid * DSB;
+            int lanev = lane;
+            asm volatile("" : "+v"(lanev));        // addresses formed here, not hoisted out of the round loop
+            const int r16v = lanev & 15, gv = lanev >> 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4 a, c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = (__bf16)(dk[nt][j] * s.scale);
+                    c[j] = (__bf16)dv[nt][j];
+                }
+                const int choff = (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) + 8 * (gv & 1);
+                *(bf16x4*)(tk + r16v * ROWB + choff) = a;
+                *(bf16x4*)(tv + r16v * DSB + choff) = c;
+            }
+#pragma unroll
+            for (int i = 0; i < CPR / 4; ++i) {
+                const int row = lanev / CPR + i * (64 / CPR), c = lanev % CPR;
+                const int choff = (c ^ (row & (CPR - 1))) << 4;
+                const u32x4 x = *(const u32x4*)(tk + row * ROWB + choff);
+                const u32x4 y = *(const u32x4*)(tv + row * DSB + choff);
+                const int krow = grp * 16 + row;
+                if (krow < s.Kn) {
+                    *(u32x4*)(dKb + (int64_t)krow * s.k_sr + c * 8) = x;
+                    *(u32x4*)(dVb + (int64_t)krow * s.v_sr + c * 8) = y;
+                }
+            }
+        }
+    }
+
+    // dQ^T accumulators -> row-major through the same private rows (every wave passed the last barrier)
+    {
+        uint8_t* tq = k_lds + 16 * wid * ROWB;
+        int lanev = lane;
+        asm volatile("" : "+v"(lanev));
+        const int r16v = lanev & 15, gv = lanev >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4 o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = (__bf16)(dq[nt][j] * s.scale);
+            *(bf16x4*)(tq + r16v * ROWB + (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) + 8 * (gv & 1)) = o4;
+        }
+#pragma unroll
+        for (int i = 0; i < CPR / 4; ++i) {
+            const int row = lanev / CPR + i * (64 / CPR), c = lanev % CPR;
+            const u32x4 x = *(const u32x4*)(tq + row * ROWB + ((c ^ (row & (CPR - 1))) << 4));
+            const int q = qw0 + row;
+            if (q < s.L) *(u32x4*)(dQ + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)q * s.q_sr + c * 8) = x;
+        }
+    }
+}
+
 // dbias[b,j] (+)= sum_h dbias_part[b,h,j]   (fixed order over heads)
 __global__ void xattn_dbias_reduce_kernel(const float* __restrict__ part, int B, int H, int Kn, int bias_len,
                                           int accumulate, float* __restrict__ dbias) {
@@ -1294,6 +1640,25 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
                          void* dq, void* dk, void* dv, float* delta, float* dbias_part, hipStream_t st) {
     const int smem_dq = DqLds<HD, NG>::BYTES;
     static const char* dq_force = getenv("STAR_XA_DQ");        // "gen" = always the general variant (A/B runs)
+    static const char* bwd_force = getenv("STAR_XA_BWD");      // "split" = never the fused kernel, "fused" = whenever legal
+    if constexpr (HD == 64 || HD == 128) {
+        static const char* dkv_force0 = getenv("STAR_XA_DKV");
+        const bool fused_ok = s->L <= BwdFused<HD>::QROWS && !dq_force && !dkv_force0;
+        const bool want = bwd_force ? (bwd_force[0] == 'f') : ((int64_t)s->B * s->h >= 192);
+        if (fused_ok && want) {
+            const int smem_f = BwdFused<HD>::BYTES;
+            static bool done_fused[64] = {};
+            if (!reserve_lds((const void*)xattn_bwd_fused_small_kernel<HD>, smem_f, done_fused)) {
+                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_f);
+                return STAR_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL((xattn_bwd_fused_small_kernel<HD>), dim3(1, s->h, s->B), dim3(512), smem_f, st,
+                               (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
+                               (const __bf16*)do_, lse, bias, key_len, *s, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv,
+                               dbias_part, getenv("STAR_XA_DBG") ? atoi(getenv("STAR_XA_DBG")) : 0);
+            return STAR_OK;
+        }
+    }
     bool dq_done = false;
     if constexpr (HD == 64 || HD == 128) {
         if (!dq_force) {
