@@ -1332,15 +1332,24 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         float db = 0.f;
         const bool grp_live = grp * 16 < kend;
 
+        // slices whose queries cannot see this group (ILK: the early ones; a group past the last key: all of them)
+        // only leave zeros in the dS tile.  Two loops, not a `continue`: a skip path inside the compute loop makes
+        // the compiler copy all 64 accumulator registers around the back edge of every iteration.
+        int sl_first = (s.ilk_diag >= 0) ? (max(grp * 16 - s.ilk_diag, 0) >> 5) : 0;
+        if (!grp_live || (dbg & 4)) sl_first = nslices;
+        sl_first = min(sl_first, nslices);
 #pragma unroll 1
-        for (int sl = 0; sl < nslices; ++sl) {
+        for (int sl = 0; sl < sl_first; ++sl) {
+            *(uint2*)(ds_row + (((4 * sl + (g >> 1)) ^ sw_ds_row) << 4)) = make_uint2(0u, 0u);
+            *(uint2*)(ds_row + (((4 * sl + 2 + (g >> 1)) ^ sw_ds_row) << 4)) = make_uint2(0u, 0u);
+        }
+#pragma unroll 1
+        for (int sl = sl_first; sl < nslices; ++sl) {
             const int q0 = sl * 32;
             const int dsc0 = ((4 * sl + (g >> 1)) ^ sw_ds_row) << 4, dsc1 = ((4 * sl + 2 + (g >> 1)) ^ sw_ds_row) << 4;
-            if ((dbg & 4) || !grp_live || (s.ilk_diag >= 0 && grp * 16 > q0 + 31 + s.ilk_diag)) {       // wave-uniform
-                *(uint2*)(ds_row + dsc0) = make_uint2(0u, 0u);
-                *(uint2*)(ds_row + dsc1) = make_uint2(0u, 0u);
-                continue;
-            }
+            // no mask needed: every key of the group is valid and visible to every query of the slice
+            const bool plain = (grp * 16 + 16 <= kend) && (q0 + 32 <= s.L) &&
+                               (s.ilk_diag < 0 || grp * 16 + 15 - s.ilk_diag <= q0);
             // S[q][key], dP[q][key] and the softmax arithmetic for two 16-query tiles, one after the other (the
             // HD = 128 kernel has no room for the fragments of both at once next to the dK / dV / dQ accumulators).
             // The wave's own K rows come back from the LDS copy made for phase C (program order: no barrier needed),
@@ -1385,16 +1394,28 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                         qt[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
                     }
                 }
-                // visibility of (query, key): key valid, query < L, key <= query + diag  <=>  qmin <= query < L
+                if (plain) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int qq = q0 + 16 * t + 4 * g + j;
-                    float p = __builtin_amdgcn_exp2f(sacc[j] * scale2 + my_bias2 - ll[j]);
-                    p = (qq >= qmin && qq < s.L) ? p : 0.f;
-                    const float ds = p * (pacc[j] - dd[j]);
-                    db += ds;
-                    pf[4 * t + j] = (__bf16)p;
-                    df[4 * t + j] = (__bf16)ds;
+                    for (int j = 0; j < 4; ++j) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j], scale2, my_bias2 - ll[j]));
+                        const float ds = p * (pacc[j] - dd[j]);
+                        db += ds;
+                        pf[4 * t + j] = (__bf16)p;
+                        df[4 * t + j] = (__bf16)ds;
+                    }
+                } else {
+                    // visibility of (query, key): key valid, query < L, key <= query + diag  <=>  qmin <= query < L
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int qq = q0 + 16 * t + 4 * g + j;
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j], scale2, my_bias2 - ll[j]));
+                        const bool vis = (qq >= qmin) & (qq < s.L);
+                        p = vis ? p : 0.f;
+                        const float ds = p * (pacc[j] - dd[j]);
+                        db += ds;
+                        pf[4 * t + j] = (__bf16)p;
+                        df[4 * t + j] = (__bf16)ds;
+                    }
                 }
             }
             // dS of (this key, queries q0+16t+4g .. +3) for phase C
