@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
     const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dQ,
-    __bf16* __restrict__ dK, __bf16* __restrict__ dV, float* __restrict__ dbias_part, int dbg) {
+    __bf16* __restrict__ dK, __bf16* __restrict__ dV, float* __restrict__ dbias_part) {
     using C = DkvSmall<HD>;
     using F = BwdFused<HD>;
     constexpr int NTH = 512, QROWS = F::QROWS, ROWB = F::ROWB, DSB = F::DSB;
@@ -1324,6 +1324,17 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         uint8_t* krow_lds = k_lds + (16 * wid + r16) * ROWB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) *(bf16x8*)(krow_lds + (((4 * ks + g) ^ sw_row) << 4)) = kfr[ks];
+        // HD = 128 reads its K rows back from that copy, so the next round's K fragments can be requested right away
+        // (into the same registers) and have the whole slice loop to arrive
+        const int ng = grp + F::WAVES;
+        const int nkey = min((ng < ngroups ? ng : grp) * 16 + r16, s.Kn - 1);
+        if constexpr (HD == 128) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kfr[ks]));      // the LDS copy first
+            const __bf16* krow = Kb + (int64_t)nkey * s.k_sr + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(krow + ks * 32);
+        }
         uint8_t* ds_row = ds_lds + (16 * wid + r16) * DSB + 8 * (g & 1);
 
         f32x4 dk[NT], dv[NT];
@@ -1336,7 +1347,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         // only leave zeros in the dS tile.  Two loops, not a `continue`: a skip path inside the compute loop makes
         // the compiler copy all 64 accumulator registers around the back edge of every iteration.
         int sl_first = (s.ilk_diag >= 0) ? (max(grp * 16 - s.ilk_diag, 0) >> 5) : 0;
-        if (!grp_live || (dbg & 4)) sl_first = nslices;
+        if (!grp_live) sl_first = nslices;
         sl_first = min(sl_first, nslices);
 #pragma unroll 1
         for (int sl = 0; sl < sl_first; ++sl) {
@@ -1452,13 +1463,11 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         // no room for a second set next to the dQ accumulators.  They are in flight across the barrier and phase C and
         // are waited for BEFORE this round's stores are issued (vmcnt retires in order).
         {
-            const int ng = grp + F::WAVES;
-            const int nkey = (dbg & 8) ? r16 : min((ng < ngroups ? ng : grp) * 16 + r16, s.Kn - 1);
             const __bf16* krow = Kb + (int64_t)nkey * s.k_sr + g * 8;
             const __bf16* vrow = Vb + (int64_t)nkey * s.v_sr + g * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                kfr[ks] = *(const bf16x8*)(krow + ks * 32);
+                if constexpr (HD != 128) kfr[ks] = *(const bf16x8*)(krow + ks * 32);
                 vfr[ks] = *(const bf16x8*)(vrow + ks * 32);
             }
             bias_cur = 0.f;
@@ -1468,7 +1477,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         xa_lds_barrier();          // K rows and dS of the whole round are in LDS
 
         // phase C: this wave's 16 queries against the round's keys
-        if (wave_has_q && !(dbg & 2)) {
+        if (wave_has_q) {
 #pragma unroll 1
             for (int kk = 0; kk < F::KROWS / 32; ++kk) {
                 const int k0 = rnd * F::KROWS + 32 * kk;
@@ -1502,7 +1511,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         // dK / dV of the round leave through the wave's own 16 rows of the K and dS tiles (free until the next
         // round's writes, which follow in program order): accumulator layout -> row-major, so that every store
         // instruction writes whole 16-byte-per-lane rows instead of 32-byte fragments of 16 rows
-        if (!(dbg & 1)) {
+        {
             uint8_t* tk = k_lds + 16 * wid * ROWB;
             uint8_t* tv = ds_lds + 16 * wid * DSB;
             int lanev = lane;
@@ -1676,7 +1685,7 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
             hipLaunchKernelGGL((xattn_bwd_fused_small_kernel<HD>), dim3(1, s->h, s->B), dim3(512), smem_f, st,
                                (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
                                (const __bf16*)do_, lse, bias, key_len, *s, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv,
-                               dbias_part, getenv("STAR_XA_DBG") ? atoi(getenv("STAR_XA_DBG")) : 0);
+                               dbias_part);
             return STAR_OK;
         }
     }
