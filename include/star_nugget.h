@@ -216,6 +216,12 @@ int star_xattn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    const float* lse, const float* bias, const int32_t* key_len,
                    const star_xattn_shape* s, void* dq, void* dk, void* dv, float* delta,
                    float* dbias_part, float* dbias, int accumulate, void* stream);
+/* Bias gradient of several decoder layers at once: dbias[b,j] = sum_l sum_h parts[l][b,h,j] in the fixed order
+ * (layer, head).  parts_host: HOST array of nl (<= 32) device pointers to the dbias_part [B,h,Kn] buffers the
+ * per-layer star_xattn_bwd calls filled (called with dbias == NULL).  Replaces the per-layer head reduction plus
+ * autograd's nl-1 additions of the reference's shared scorer_logits gradient (my_transformer.py:917-928, 582-589). */
+int star_xattn_dbias_sum(const float* const* parts_host, int nl, int B, int h, int Kn, int bias_len,
+                         float* dbias, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ reference's operator signatures), `step.py` (the NuggetStep used by smoke/bench)
 """
 from . import ops  # noqa: F401
 from .nugget import (NuggetCrossAttention, NuggetOpsMixin, NuggetScorer, gather_nuggets,  # noqa: F401
-                     score_biased_attn)
+                     score_biased_attn, share_scorer_logits)
 
 __all__ = ["ops", "NuggetScorer", "NuggetOpsMixin", "NuggetCrossAttention", "gather_nuggets",
-           "score_biased_attn"]
+           "score_biased_attn", "share_scorer_logits"]

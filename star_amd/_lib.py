@@ -42,6 +42,7 @@ SIGNATURES = {
     "star_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I64, _P]),
     "star_gather_rows_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "star_diag_fanout_fwd": (_I, [_P, _P, _I, _I64, _I, _P, _P]),
+    "star_xattn_dbias_sum": (_I, [C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _P, _P]),
     "star_diag_fanout_bwd": (_I, [C.POINTER(C.c_void_p), _I, _P, _I64, _I, _P, _P]),
     "star_cif_quantity_fwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
     "star_cif_quantity_bwd": (_I, [_P, _P, _P, _F, _I, _I, _I, _P, _P]),

@@ -1579,6 +1579,25 @@ __global__ void xattn_dbias_reduce_kernel(const float* __restrict__ part, int B,
     *o = accumulate ? *o + sum : sum;
 }
 
+// dbias[b,j] = sum_l sum_h part_l[b,h,j]: the bias-gradient partials of ALL decoder layers in one launch (the
+// reference feeds the same scorer_logits to every layer, my_transformer.py:917-928), fixed order (layer, head)
+constexpr int DBIAS_MAX_LAYERS = 32;
+struct DbiasParts {
+    const float* p[DBIAS_MAX_LAYERS];
+};
+__global__ void xattn_dbias_sum_kernel(DbiasParts parts, int nl, int B, int H, int Kn, int bias_len,
+                                       float* __restrict__ dbias) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= bias_len) return;
+    float sum = 0.f;
+    for (int l = 0; l < nl; ++l) {
+        const float* part = parts.p[l] + (int64_t)b * H * Kn + j;
+        for (int h = 0; h < H; ++h) sum += part[(int64_t)h * Kn];
+    }
+    dbias[(int64_t)b * bias_len + j] = sum;
+}
+
 // P[b,h,q,key] = exp(logit - lse): the optional attention-weights output (output_attentions)
 template <int HD>
 __global__ __launch_bounds__(XA_THREADS) void xattn_probs_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ K,
@@ -1809,5 +1828,23 @@ extern "C" int star_xattn_bwd(const void* q, const void* k, const void* v, const
     }
     if (rc) return rc;
     STAR_LAUNCH_CHECK("star_xattn_bwd");
+    return STAR_OK;
+}
+
+extern "C" int star_xattn_dbias_sum(const float* const* parts_host, int nl, int B, int h, int Kn, int bias_len,
+                                    float* dbias, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(parts_host && dbias, "star_xattn_dbias_sum: null pointer");
+    STAR_REQUIRE(nl >= 1 && nl <= DBIAS_MAX_LAYERS, "star_xattn_dbias_sum: %d layers not in [1, %d]", nl, DBIAS_MAX_LAYERS);
+    STAR_REQUIRE(B >= 1 && B <= 65535 && h >= 1 && Kn >= 1 && bias_len >= 1 && bias_len <= Kn,
+                 "star_xattn_dbias_sum: bad shape B=%d h=%d Kn=%d bias_len=%d", B, h, Kn, bias_len);
+    DbiasParts parts = {};
+    for (int l = 0; l < nl; ++l) {
+        STAR_REQUIRE(parts_host[l], "star_xattn_dbias_sum: parts[%d] is null", l);
+        parts.p[l] = parts_host[l];
+    }
+    hipLaunchKernelGGL(xattn_dbias_sum_kernel, dim3(cdiv(bias_len, 256), B), dim3(256), 0, (hipStream_t)stream, parts, nl,
+                       B, h, Kn, bias_len, dbias);
+    STAR_LAUNCH_CHECK("star_xattn_dbias_sum");
     return STAR_OK;
 }

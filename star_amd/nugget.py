@@ -146,6 +146,12 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
         scale = scale / float(layer_idx + 1)
     bias = None
     B, K = query.shape[0], key.shape[2]
+    if scorer_logits is not None and scorer_logits.dim() == 3:
+        # a per-layer view from share_scorer_logits(): the encoder mask is already folded in
+        if scorer_logits.shape[2] != K:
+            raise ValueError(f"shared scorer_logits cover {scorer_logits.shape[2]} keys but there are {K}")
+        return ops.xattn(query, key, value, bias=scorer_logits, key_len=key_lengths,
+                         ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions)
     if attention_mask is not None:
         if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
             raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
@@ -160,6 +166,27 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
     out, probs = ops.xattn(query, key, value, bias=bias, key_len=key_lengths,
                            ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions)
     return out, probs
+
+
+def share_scorer_logits(scorer_logits, n_layers: int, n_heads: int, attention_mask=None, n_keys=None):
+    """The reference hands the same scorer_logits [B,Kb] (and the same additive encoder mask [B,1,1,K]) to every
+    decoder block (my_transformer.py:917-928), so autograd reduces the bias gradient over heads once per layer and
+    then adds the layers up.  Call this once per forward (in MyGPT2Model.forward, before the block loop) and pass
+    element i of the result as `scorer_logits` of block i: mask and logits are folded into one bias, every layer
+    gets a [B,h,K] broadcast view of it, and the backward sums all layers' per-head partials in one launch.
+    Blocks that receive such a view ignore their `encoder_attention_mask` (it is already inside)."""
+    s = scorer_logits.to(torch.float32)
+    B = s.shape[0]
+    K = n_keys if n_keys is not None else (attention_mask.shape[-1] if attention_mask is not None else s.shape[1])
+    if s.shape[1] > K:
+        raise ValueError(f"scorer_logits has {s.shape[1]} columns but there are only {K} keys")
+    if s.shape[1] < K:
+        s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
+    if attention_mask is not None:
+        if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
+            raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
+        s = attention_mask.reshape(B, K).to(torch.float32) + s
+    return ops.share_bias(s, n_layers, n_heads)
 
 
 class Conv1D(nn.Module):

@@ -491,8 +491,16 @@ class _XAttn(torch.autograd.Function):
         # output in [B, L, h, hd] memory order (what merge_heads wants), exposed as [B,h,L,hd]
         o = torch.empty((B, L, h, hd), dtype=torch.bfloat16, device=dev).permute(0, 2, 1, 3)
         lse = torch.empty((B, h, L), dtype=torch.float32, device=dev)
+        per_head = bias is not None and bias.dim() == 3
+        if per_head:
+            # [B,h,K] view made by share_bias(): the same [B,K] logits for every head (stride 0 over heads); the
+            # gradient then leaves as the per-head partials and share_bias() reduces all layers in one launch
+            if bias.shape[1] != h or bias.stride(1) != 0:
+                raise ValueError("xattn: a 3-d bias must be a [B,h,K] broadcast of [B,K] logits (see share_bias)")
+            bias = bias[:, 0, :]
         bias_f = None if bias is None else bias.detach().to(torch.float32).contiguous()
         bias_len = 0 if bias_f is None else bias_f.shape[1]
+        ctx.bias_per_head = per_head
         kl = None if key_len is None else key_len.to(torch.int32).contiguous()
         probs = torch.empty((B, h, L, kb.shape[2]), dtype=torch.float32, device=dev) if need_probs else None
         s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
@@ -532,7 +540,8 @@ class _XAttn(torch.autograd.Function):
         dbias = part = None
         if bias_f is not None:
             part = torch.empty((B, h, Kn), dtype=torch.float32, device=dev)
-            dbias = torch.empty((B, bias_len), dtype=torch.float32, device=dev)
+            if not ctx.bias_per_head:
+                dbias = torch.empty((B, bias_len), dtype=torch.float32, device=dev)
         s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
         check(lib().star_xattn_bwd(ptr(qb), ptr(kb), ptr(vb), ptr(o), ptr(go), ptr(lse), ptr(bias_f), ptr(kl), s,
                                    ptr(dq), ptr(dk), ptr(dv), ptr(delta), ptr(part), ptr(dbias), 0, stream_ptr()),
@@ -540,9 +549,54 @@ class _XAttn(torch.autograd.Function):
         dt = ctx.in_dtype
         if dt != torch.bfloat16:
             dq, dk, dv = dq.to(dt), dk.to(dt), dv.to(dt)
+        if ctx.bias_per_head:
+            dbias = part if bias_len == Kn else part[:, :, :bias_len]
         if dbias is not None and ctx.bias_dtype != torch.float32:
             dbias = dbias.to(ctx.bias_dtype)
         return dq, dk, dv, dbias, None, None, None, None
+
+
+class _ShareBias(torch.autograd.Function):
+    """One [B,K] tensor of scorer logits handed to nl decoder layers (my_transformer.py:917-928): forward gives every
+    layer a [B,h,K] broadcast view, backward sums the layers' per-head gradient partials in ONE launch
+    (star_xattn_dbias_sum) instead of nl head reductions plus nl-1 additions by autograd."""
+
+    @staticmethod
+    def forward(ctx, bias, nl, h):
+        ctx.set_materialize_grads(False)
+        b = bias.detach()
+        ctx.meta = (nl, h, tuple(bias.shape), bias.dtype)
+        return tuple(b.unsqueeze(1).expand(b.shape[0], h, b.shape[1]) for _ in range(nl))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        nl, h, (B, K), dtype = ctx.meta
+        parts = [g for g in grads if g is not None]
+        if not parts:
+            return None, None, None
+        fixed = []
+        for g in parts:
+            # the attention backward hands over its [B,h,Kn] scratch (possibly a [:, :, :K] slice of it)
+            if g.dtype != torch.float32 or g.stride(2) != 1 or g.stride(0) != h * g.stride(1):
+                g = g.to(torch.float32).contiguous()
+            fixed.append(g)
+        kn = {g.stride(1) for g in fixed}
+        if len(kn) != 1 or len(fixed) > 32:
+            out = sum(g.sum(1) for g in fixed)                      # mixed layouts: plain torch reduction
+        else:
+            out = torch.empty((B, K), dtype=torch.float32, device=fixed[0].device)
+            arr = (_lib.C.c_void_p * len(fixed))(*[g.data_ptr() for g in fixed])
+            check(lib().star_xattn_dbias_sum(arr, len(fixed), B, h, kn.pop(), K, ptr(out), stream_ptr()),
+                  "star_xattn_dbias_sum")
+        return out.to(dtype), None, None
+
+
+def share_bias(bias, n_layers: int, n_heads: int):
+    """bias [B,K] -> tuple of n_layers [B,h,K] broadcast views to pass as `bias` of xattn(), one per decoder layer."""
+    _need_cuda(bias)
+    if bias.dim() != 2:
+        raise ValueError("share_bias: bias must be [B, K]")
+    return _ShareBias.apply(bias, int(n_layers), int(n_heads))
 
 
 def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[float] = None,

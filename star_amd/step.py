@@ -78,11 +78,12 @@ def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag, with_loss: bool):
     B, K, d = mem.shape
     h = inp.qs[0].shape[1]
     kvs = ops.diag_fanout(mem, inp.kv_scales_flat)
+    biases = ops.share_bias(bias, len(inp.qs), h)       # one bias-gradient reduction for all layers
     outs = []
     for l, q in enumerate(inp.qs):
         k = kvs[2 * l].view(B, K, h, d // h).permute(0, 2, 1, 3)
         v = kvs[2 * l + 1].view(B, K, h, d // h).permute(0, 2, 1, 3)
-        o, _ = ops.xattn(q, k, v, bias=bias, key_len=key_len, ilk_diag=ilk_diag)
+        o, _ = ops.xattn(q, k, v, bias=biases[l], key_len=key_len, ilk_diag=ilk_diag)
         outs.append(o)
     loss = None
     if with_loss:

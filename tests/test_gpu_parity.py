@@ -384,6 +384,32 @@ def test_xattn_random_vs_oracle(ops, B, h, L, K, hd, ilk):
     close(dsc, scr.grad, "dscores")
 
 
+@pytest.mark.parametrize("B,h,L,K,hd,nl", [(3, 4, 50, 90, 64, 3), (24, 8, 64, 140, 128, 2)])
+def test_shared_scorer_logits_grad(ops, B, h, L, K, hd, nl):
+    """share_scorer_logits: nl layers fed from one logits tensor; gradient = the per-layer path's (one launch sums
+    the [B,h,K] partials of all layers instead of nl head reductions + autograd adds)."""
+    from star_amd.nugget import score_biased_attn, share_scorer_logits
+    g = torch.Generator().manual_seed(B + K)
+    mk = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+    qs, ks, vs, gs = ([mk(B, h, n, hd) for _ in range(nl)] for n in (L, K, K, L))
+    klen = [K] + [max(3, K - 11 * (i + 1)) for i in range(B - 1)]
+    kmask = lmask(klen, K)
+    add = dev(((1.0 - kmask[:, None, None, :].astype(np.float32)) * np.finfo(np.float32).min))
+    sc0 = torch.randn(B, K, generator=g).to(DEV)
+    res = []
+    for shared in (False, True):
+        sc = sc0.clone().requires_grad_()
+        per_layer = share_scorer_logits(sc, nl, h, attention_mask=add) if shared else [sc] * nl
+        outs = [score_biased_attn(qs[l], ks[l], vs[l], add, None, per_layer[l], limit_cross_attn=(l % 2 == 1))[0]
+                for l in range(nl)]
+        torch.autograd.backward(outs, gs)
+        res.append((outs, sc.grad))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    ref, got = res[0][1].cpu().numpy(), res[1][1].cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+
+
 def test_xattn_strided_views(ops):
     """K/V as [B,K,h,hd] -> permuted views (what split_heads produces) must give the same result as dense copies."""
     g = torch.Generator().manual_seed(5)
