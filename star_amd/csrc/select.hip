@@ -102,7 +102,8 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
     uint32_t* keys = smem;                        // [T]
     uint32_t* hist = keys + T;                    // [256]
     uint32_t* misc = hist + 256;                  // [16]
-    uint8_t* cls = (uint8_t*)(misc + 16);         // [T]
+    float* sraw = (float*)(misc + 16);            // [T] the scores as read (gathered again at the end)
+    uint8_t* cls = (uint8_t*)(sraw + T);          // [T]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.x;
     const float* srow = scores + (size_t)b * T;
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
     const uint32_t key_last = order_key(3.4028234663852886e38f);
     for (int i = tid; i < T; i += SEL_THREADS) {
         bool valid = mrow ? (mrow[i] != 0) : (i < n_tok);
-        uint32_t key = valid ? order_key(srow[i]) : key_pad;
+        const float sv = srow[i];
+        sraw[i] = sv;
+        uint32_t key = valid ? order_key(sv) : key_pad;
         if (i == n_tok - 1) key = key_last;
         keys[i] = key;
     }
@@ -147,7 +150,12 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
 
     uint32_t v1 = 0xFFFFFFFFu, need1 = 0, v2, need2;
     if (kb > 0) radix_select(keys, T, (uint32_t)kb, hist, misc, v1, need1);
-    radix_select(keys, T, (uint32_t)K, hist, misc, v2, need2);
+    if (kb == K) {           // a full-length utterance: the top-K set is the kept set (block-uniform branch)
+        v2 = v1;
+        need2 = need1;
+    } else {
+        radix_select(keys, T, (uint32_t)K, hist, misc, v2, need2);
+    }
 
     // ---- tie ranks in frame order: each thread owns a contiguous chunk of frames
     const int C = (T + SEL_THREADS - 1) / SEL_THREADS;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
         if (slot < (uint32_t)K) {
             irow[slot] = i;
             if (flat_rows) flat_rows[(size_t)b * K + slot] = b * T + i;
-            if (scores_gather) scores_gather[(size_t)b * K + slot] = srow[i];
+            if (scores_gather) scores_gather[(size_t)b * K + slot] = sraw[i];
             if (positions) positions[(size_t)b * K + slot] = (c == 1) ? (int64_t)i : (int64_t)-1;
         }
     }
@@ -232,7 +240,7 @@ extern "C" int star_topk_select(const float* scores, const uint8_t* attn_mask, c
                  "star_topk_select: give exactly one of attn_mask / lengths");
     STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && K <= T, "star_topk_select: need B>=1, 1<=K<=T (B=%d T=%d K=%d)", B, T, K);
     STAR_REQUIRE(T <= 16384, "star_topk_select: T=%d exceeds the 16384-frame LDS row limit", T);
-    size_t smem = (size_t)T * 4 + 256 * 4 + 16 * 4 + (size_t)T;
+    size_t smem = (size_t)T * 8 + 256 * 4 + 16 * 4 + (size_t)T;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)topk_select_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -1580,22 +1580,38 @@ __global__ void xattn_dbias_reduce_kernel(const float* __restrict__ part, int B,
 }
 
 // dbias[b,j] = sum_l sum_h part_l[b,h,j]: the bias-gradient partials of ALL decoder layers in one launch (the
-// reference feeds the same scorer_logits to every layer, my_transformer.py:917-928), fixed order (layer, head)
+// reference feeds the same scorer_logits to every layer, my_transformer.py:917-928), fixed summation order
 constexpr int DBIAS_MAX_LAYERS = 32;
 struct DbiasParts {
     const float* p[DBIAS_MAX_LAYERS];
 };
-__global__ void xattn_dbias_sum_kernel(DbiasParts parts, int nl, int B, int H, int Kn, int bias_len,
-                                       float* __restrict__ dbias) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void xattn_dbias_sum_kernel(DbiasParts parts, int nl, int B, int H, int Kn,
+                                                              int bias_len, float* __restrict__ dbias) {
+    // 64 columns per workgroup; the nl*H (layer, head) rows are dealt round-robin to the 4 waves so that the loads
+    // of a column are independent and in flight together, then the 4 partial sums are added in a fixed order
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: pointer table read by SALU
+    const int j = blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
-    if (j >= bias_len) return;
+    const int jc = min(j, bias_len - 1);
+    const int total = nl * H;
     float sum = 0.f;
-    for (int l = 0; l < nl; ++l) {
-        const float* part = parts.p[l] + (int64_t)b * H * Kn + j;
-        for (int h = 0; h < H; ++h) sum += part[(int64_t)h * Kn];
+    int n = w;
+    for (; n + 12 < total; n += 16) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = n + 4 * u;
+            v[u] = parts.p[m / H][((int64_t)b * H + m % H) * Kn + jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sum += v[u];
     }
-    dbias[(int64_t)b * bias_len + j] = sum;
+    for (; n < total; n += 4) sum += parts.p[n / H][((int64_t)b * H + n % H) * Kn + jc];
+    red[w][lane] = sum;
+    __syncthreads();
+    if (w == 0 && j < bias_len) dbias[(int64_t)b * bias_len + j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // P[b,h,q,key] = exp(logit - lse): the optional attention-weights output (output_attentions)
@@ -1843,7 +1859,7 @@ extern "C" int star_xattn_dbias_sum(const float* const* parts_host, int nl, int 
         STAR_REQUIRE(parts_host[l], "star_xattn_dbias_sum: parts[%d] is null", l);
         parts.p[l] = parts_host[l];
     }
-    hipLaunchKernelGGL(xattn_dbias_sum_kernel, dim3(cdiv(bias_len, 256), B), dim3(256), 0, (hipStream_t)stream, parts, nl,
+    hipLaunchKernelGGL(xattn_dbias_sum_kernel, dim3(cdiv(bias_len, 64), B), dim3(256), 0, (hipStream_t)stream, parts, nl,
                        B, h, Kn, bias_len, dbias);
     STAR_LAUNCH_CHECK("star_xattn_dbias_sum");
     return STAR_OK;
