@@ -151,6 +151,19 @@ int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype, const flo
                            const int32_t* counts, int B, int T, int cap, int d, void* ds,
                            float* dalphas, float* workspace, void* stream);
 
+/* ---------------------------------------------------------------- 8f-3: nugget type embedding
+ * Replaces  inputs_embed = encoder_out.last_hidden_state + semantic_encoder.type_embed(type_ind_table)
+ * (w2v_asr.py:383,400,456,560; w2v_simul.py:432; type_embed = nn.Embedding(2, d), my_transformer.py:761).
+ * x, out [N,d] (N = B*T rows), table [N] int64 (0 / non-zero = plain frame / nugget), emb [2,d]; x, emb, out share
+ * dtype (STAR_DT_BF16 / STAR_DT_F32); the sum is formed in fp32 and rounded once (what torch's add does). */
+int star_type_embed_add(const void* x, const int64_t* table, const void* emb, int dtype, int64_t N, int d,
+                        void* out, void* stream);
+/* Its backward for the embedding table: demb[c][:] = sum of dout rows whose table entry is c, fp32 [2,d], in a fixed
+ * summation order (d x = dout needs no kernel).  workspace: star_type_embed_grad_workspace(N, d, dtype) bytes. */
+size_t star_type_embed_grad_workspace(int64_t N, int d, int dtype);
+int star_type_embed_grad(const void* dout, const int64_t* table, int dtype, int64_t N, int d, float* demb,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- a1: scorer MLP
  * Replaces nugget_model = Sequential(Linear(d,d), ReLU, Linear(d,1)) + squeeze(-1)
  * (w2v_asr.py:113-117,553; w2v_simul.py:144-148,410-411).

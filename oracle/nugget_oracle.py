@@ -248,6 +248,13 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     return p @ v, p
 
 
+# ------------------------------------------------------------------ 8f-3: nugget type embedding
+def type_embed_add(x: torch.Tensor, table: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """inputs_embed = encoder_out.last_hidden_state + semantic_encoder.type_embed(type_ind_table)
+    (w2v_asr.py:383,400,456,560; w2v_simul.py:432), type_embed = nn.Embedding(2, d) (my_transformer.py:761)."""
+    return x + weight[table.long()]
+
+
 # ------------------------------------------------------------------ 8f-2: CIF weighted aggregation
 def cif_aggregate(alphas: torch.Tensor, s: torch.Tensor, threshold: float = 1.0):
     """Continuous integrate-and-fire weighted aggregation (w2v_simul.py:558-606; same loop at w2v_asr.py:681-722).

@@ -41,6 +41,9 @@ SIGNATURES = {
     "star_nugget_type_table": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "star_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I64, _P]),
     "star_gather_rows_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "star_type_embed_add": (_I, [_P, _P, _P, _I, _I64, _I, _P, _P]),
+    "star_type_embed_grad_workspace": (C.c_size_t, [_I64, _I, _I]),
+    "star_type_embed_grad": (_I, [_P, _P, _I, _I64, _I, _P, _P, C.c_size_t, _P]),
     "star_diag_fanout_fwd": (_I, [_P, _P, _I, _I64, _I, _P, _P]),
     "star_xattn_dbias_sum": (_I, [C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _P, _P]),
     "star_diag_fanout_bwd": (_I, [C.POINTER(C.c_void_p), _I, _P, _I64, _I, _P, _P]),

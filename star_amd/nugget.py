@@ -89,6 +89,13 @@ class NuggetOpsMixin:
         return ops.cif_resize(alphas, target_lengths, threshold=threshold)
 
     @staticmethod
+    def add_type_embedding(inputs_embed: torch.Tensor, type_ind_table: torch.Tensor, type_embed):
+        """`inputs_embed + self.semantic_encoder.type_embed(type_ind_table)` (w2v_asr.py:383,400,456,560;
+        w2v_simul.py:432) in one pass; `type_embed` is the nn.Embedding(2, d) module or its weight."""
+        weight = type_embed.weight if isinstance(type_embed, nn.Module) else type_embed
+        return ops.type_embed_add(inputs_embed, type_ind_table, weight)
+
+    @staticmethod
     def cif_weighted_aggregate(alphas: torch.Tensor, semantic_repr: torch.Tensor, threshold: float = 1.0):
         """The integrate-and-fire frame loop of lm_cif_training (w2v_simul.py:558-606; w2v_asr.py:681-722) as one
         call: -> (cif_repr [B,Kf,d], cif_attn_mask [B,Kf] fp32 0/1, fired positions [B,Kf] int64 with -1 pads),

@@ -556,6 +556,59 @@ class _XAttn(torch.autograd.Function):
         return dq, dk, dv, dbias, None, None, None, None
 
 
+class _TypeEmbedAdd(torch.autograd.Function):
+    """x + type_embed(table) in one pass (w2v_asr.py:560); d x = d out, d weight by a two-stage column reduction."""
+
+    @staticmethod
+    def forward(ctx, x, table, weight):
+        ctx.set_materialize_grads(False)
+        xd, wd = x.detach().contiguous(), weight.detach().to(x.dtype).contiguous()
+        tb = table.detach().to(torch.int64).contiguous()
+        d = xd.shape[-1]
+        out = torch.empty_like(xd)
+        dt = DT_BF16 if xd.dtype == torch.bfloat16 else DT_F32
+        check(lib().star_type_embed_add(ptr(xd), ptr(tb), ptr(wd), dt, xd.numel() // d, d, ptr(out), stream_ptr()),
+              "star_type_embed_add")
+        ctx.save_for_backward(tb)
+        ctx.meta = (dt, d, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        (tb,) = ctx.saved_tensors
+        dt, d, wdtype = ctx.meta
+        dw = None
+        if ctx.needs_input_grad[2]:
+            gd = g.detach()
+            want = torch.bfloat16 if dt == DT_BF16 else torch.float32
+            if gd.dtype != want or not gd.is_contiguous():
+                gd = gd.to(want).contiguous()
+            n = gd.numel() // d
+            nbytes = lib().star_type_embed_grad_workspace(n, d, dt)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=gd.device)
+            dwf = torch.empty((2, d), dtype=torch.float32, device=gd.device)
+            check(lib().star_type_embed_grad(ptr(gd), ptr(tb), dt, n, d, ptr(dwf), ptr(ws), nbytes, stream_ptr()),
+                  "star_type_embed_grad")
+            dw = dwf.to(wdtype)
+        return (g if ctx.needs_input_grad[0] else None), None, dw
+
+
+def type_embed_add(x, table, weight):
+    """inputs_embed = x + weight[table]  (x [..., d] bf16/fp32, table [...] 0/1, weight [2, d])."""
+    _need_cuda(x, table, weight)
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("type_embed_add: bf16 or fp32 only")
+    if weight.dim() != 2 or weight.shape[0] != 2 or weight.shape[1] != x.shape[-1]:
+        raise ValueError(f"type_embed_add: weight must be [2, {x.shape[-1]}], got {tuple(weight.shape)}")
+    if tuple(table.shape) != tuple(x.shape[:-1]):
+        raise ValueError(f"type_embed_add: table {tuple(table.shape)} does not match x {tuple(x.shape)}")
+    if x.shape[-1] % (8 if x.dtype == torch.bfloat16 else 4):
+        raise ValueError("type_embed_add: the hidden size must be a multiple of 16 bytes")
+    return _TypeEmbedAdd.apply(x, table, weight)
+
+
 class _ShareBias(torch.autograd.Function):
     """One [B,K] tensor of scorer logits handed to nl decoder layers (my_transformer.py:917-928): forward gives every
     layer a [B,h,K] broadcast view, backward sums the layers' per-head gradient partials in ONE launch

@@ -385,8 +385,33 @@ def gen_e2e():
     _run_e2e("simul", True, 103)
 
 
+# ------------------------------------------------------------------ 8f-3: type embedding added to the encoder states
+def gen_type_embed():
+    """The reference lines `table, pos = self.add_nugget_type_embedding(x, idx, mask)` and
+    `inputs_embed = x + self.semantic_encoder.type_embed(table)` (w2v_asr.py:559-560), forward and backward, with the
+    reference's own compression picking the nuggets; type_embed = nn.Embedding(2, d) as in my_transformer.py:761."""
+    asr = w2v_asr.W2VASRModel
+    for name, (B, T, d, lengths, rate, seed) in {"a": (3, 50, 64, [50, 41, 7], 4, 31),
+                                                 "b": (2, 33, 128, [33, 20], 12, 32)}.items():
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, T, d, generator=g, requires_grad=True)
+        scores = torch.randn(B, T, generator=g)
+        mask = len_mask(lengths, T)
+        emb = torch.nn.Embedding(2, d)
+        with torch.no_grad():
+            emb.weight.copy_(torch.randn(2, d, generator=g) * 0.1)
+        ns = SimpleNamespace(nugget_compress_rate=rate, nugget_model=None)
+        nmask, idx, _ = asr.apply_nugget_compression(ns, x, mask, nugget_scores=scores)
+        table, pos = asr.add_nugget_type_embedding(x, idx, nmask)
+        out = x + emb(table)
+        gout = torch.randn(B, T, d, generator=g)
+        (out * gout).sum().backward()
+        save(f"typeembed_{name}", x=x, lengths=np.array(lengths), scores=scores, rate=rate, emb=emb.weight, table=table,
+             out=out, gout=gout, dx=x.grad, demb=emb.weight.grad)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg):
+    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed):
         if not only or fn.__name__ in only:
             fn()

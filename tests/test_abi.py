@@ -20,7 +20,8 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("star_topk_select", "star_gather_rows_fwd", "star_gather_rows_bwd", "star_cif_quantity_fwd",
                  "star_cif_resize", "star_cif_fire_scan", "star_scorer_fwd", "star_scorer_bwd", "star_xattn_fwd",
-                 "star_xattn_bwd", "star_xattn_dbias_sum", "star_last_error", "star_version"):
+                 "star_xattn_bwd", "star_xattn_dbias_sum", "star_type_embed_add", "star_type_embed_grad",
+                 "star_type_embed_grad_workspace", "star_last_error", "star_version"):
         assert must in names
 
 

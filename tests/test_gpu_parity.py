@@ -698,3 +698,42 @@ def test_cif_aggregate_random_vs_oracle(ops, B, T, d, dtype):
     atol_a = (2e-2 if dtype == torch.bfloat16 else 1e-4) * float(a_ref.grad.abs().max())
     np.testing.assert_allclose(a.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
                                atol=atol_a)
+
+
+# ------------------------------------------------------------------------------------------------ 8f-3: type embedding
+@pytest.mark.parametrize("name", ["typeembed_a", "typeembed_b"])
+def test_type_embed_golden_gpu(ops, name):
+    """x + type_embed(table) through the C ABI: forward bit-exact (fp32), d x = d out, d emb rtol 1e-5."""
+    from star_amd.nugget import NuggetOpsMixin
+    g = load(name)
+    x = dev(g["x"]).requires_grad_()
+    emb = torch.nn.Embedding(2, x.shape[-1]).to(DEV)
+    with torch.no_grad():
+        emb.weight.copy_(dev(g["emb"]))
+    out = NuggetOpsMixin.add_type_embedding(x, dev(g["table"]), emb)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), g["out"])
+    (out * dev(g["gout"])).sum().backward()
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), g["dx"])
+    np.testing.assert_allclose(emb.weight.grad.cpu().numpy(), g["demb"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,d,dtype", [(32, 1500, 1024, torch.bfloat16), (3, 77, 200, torch.float32),
+                                         (5, 130, 520, torch.bfloat16)])
+def test_type_embed_random_vs_oracle(ops, B, T, d, dtype):
+    g = torch.Generator().manual_seed(B + T + d)
+    x = torch.randn(B, T, d, generator=g).to(dtype)
+    w = (torch.randn(2, d, generator=g) * 0.1).to(dtype)
+    table = (torch.rand(B, T, generator=g) < 0.25).long()
+    gout = torch.randn(B, T, d, generator=g).to(dtype)
+    xr, wr = x.float().clone().requires_grad_(), w.float().clone().requires_grad_()
+    ref = orc.type_embed_add(xr, table, wr)
+    (ref * gout.float()).sum().backward()
+    xd, wd = x.detach().to(DEV).requires_grad_(), w.detach().to(DEV).requires_grad_()
+    out = ops.type_embed_add(xd, table.to(DEV), wd)
+    # one rounding of the fp32 sum: bit-exact against the oracle's fp32 sum cast once
+    assert torch.equal(out.detach().cpu(), ref.detach().to(dtype))
+    out.backward(gout.to(DEV))
+    assert torch.equal(xd.grad.cpu(), gout)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # d emb leaves in the weight's dtype
+    ref_dw = wr.grad.numpy()
+    np.testing.assert_allclose(wd.grad.float().cpu().numpy(), ref_dw, rtol=tol, atol=tol * np.abs(ref_dw).max())

@@ -234,3 +234,22 @@ def test_cif_aggregate_golden(name):
     (cif * torch.from_numpy(g["dcif"])).sum().backward()
     np.testing.assert_allclose(s.grad.numpy(), g["ds"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(alphas.grad.numpy(), g["dalphas"], rtol=1e-4, atol=1e-8)
+
+
+# ------------------------------------------------------------------ 8f-3: type embedding added to the encoder states
+@pytest.mark.parametrize("name", ["typeembed_a", "typeembed_b"])
+def test_type_embed_golden(name):
+    """oracle select -> type table -> x + E[table], and its gradients, against the reference call site
+    (w2v_asr.py:555-560)."""
+    g = load(name)
+    x = torch.from_numpy(g["x"]).requires_grad_()
+    emb = torch.from_numpy(g["emb"]).requires_grad_()
+    T = x.shape[1]
+    nmask, idx, _ = orc.topk_select(g["scores"], lmask(g["lengths"], T), rate=float(g["rate"]))
+    table, _ = orc.type_table(T, idx, nmask)
+    np.testing.assert_array_equal(table, g["table"])
+    out = orc.type_embed_add(x, torch.from_numpy(table), emb)
+    np.testing.assert_array_equal(out.detach().numpy(), g["out"])
+    (out * torch.from_numpy(g["gout"])).sum().backward()
+    np.testing.assert_array_equal(x.grad.numpy(), g["dx"])
+    np.testing.assert_allclose(emb.grad.numpy(), g["demb"], rtol=1e-5, atol=1e-6)
