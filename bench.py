@@ -88,9 +88,9 @@ def cpu_baseline(args, seconds):
 
 def pmc_traffic(N, d):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
-    as the gfx950 note prescribes + WRITE_SIZE; profiles/r01_v13_pmc_scorer_fwd.json).  PMC passes cannot run
+    as the gfx950 note prescribes + WRITE_SIZE; profiles/r01_v42_pmc_scorer_fwd.json).  PMC passes cannot run
     inside this process, so the figure is only reported for the exact workload it was collected on; else None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v13_pmc_scorer_fwd.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v42_pmc_scorer_fwd.json")
     try:
         with open(path) as f:
             doc = json.load(f)
