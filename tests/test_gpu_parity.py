@@ -355,6 +355,7 @@ def test_xattn_golden(ops, name, use_key_len):
                                             (25, 8, 100, 77, 64, False), (24, 8, 128, 200, 128, True),
                                             # ... B*h >= 192: the fused dQ/dK/dV kernel (rounds of 128 keys)
                                             (32, 8, 37, 300, 128, False), (26, 8, 128, 130, 64, True),
+                                            (24, 8, 100, 700, 128, True), (48, 4, 16, 17, 64, False),
                                             # ... and with the key groups split over several workgroups
                                             (2, 2, 60, 200, 64, True), (1, 3, 128, 1000, 128, False)])
 def test_xattn_random_vs_oracle(ops, B, h, L, K, hd, ilk):
