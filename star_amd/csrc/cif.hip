@@ -137,17 +137,20 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
 // ------------------------------------------------------------------------------------------ a7
 // The recurrence is inherently serial in t and fp32 addition is not associative, so a parallel prefix sum cannot
 // reproduce the reference's fire positions: every utterance runs its own exact serial recurrence (one lane each).
-// What can be parallel is everything around it: a workgroup owns a few utterances, brings their whole rows into
-// LDS with all 256 threads (coalesced), then lane r walks row r from LDS in register blocks of 16 frames; fire
-// positions are written straight from the fire bits of a block, off the dependent chain.  (The first version,
-// 64 utterances per wave on LDS-transposed 64-frame tiles, spent its time waiting on one tile load per 64 steps:
-// 212 us at B = 32, T = 1500.)
+// Everything around it is parallel: a workgroup owns a few utterances, brings their rows (alphas * mask) and the
+// per-frame thresholds (1; -inf at the last valid frame = the forced fire) into LDS with all 256 threads, lane r of
+// wave 0 runs cif_serial_chain() on row r (4 instructions per frame; the row becomes the pre-fire integrals), and all
+// threads then turn integrals into fire positions by an order-preserving compaction.
+// History at B = 32, T = 1500: 212 us (64 utterances per wave on LDS-transposed tiles), 88 us (one lane per row, but
+// thresholds, bounds tests and fire-bit bookkeeping inside the serial loop: ~280 instructions per 16 frames).
 
-// Rows per workgroup: the rows of a workgroup are resident in LDS as a whole (R * T floats, odd pitch), so the
-// serial part never touches global memory for its inputs; more, smaller workgroups = more recurrences in flight.
-static inline int scan_rows_per_wg(int T) {
+// Rows per workgroup: two arrays of R * pitch floats in LDS.
+__host__ __device__ static inline int scan_pitch(int T) { return ((T + 15) & ~15) + 4; }
+// One utterance per workgroup unless the batch is huge: the parallel phases (row load, compaction) then cost one row
+// per workgroup instead of R rows one after the other, and the serial chains still all run at the same time.
+static inline int scan_rows_per_wg(int B, int T) {
     int r = 8;
-    while (r > 1 && (size_t)r * (T | 1) * 4 > 64 * 1024) r >>= 1;
+    while (r > 1 && ((size_t)r * scan_pitch(T) * 8 > 128 * 1024 || (B + r - 1) / r < 2048)) r >>= 1;
     return r;
 }
 
@@ -156,9 +159,10 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
     const float* __restrict__ scores, int B, int T, int cap, int R, int64_t* __restrict__ idx_out,
     uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
     float* __restrict__ scores_gather) {
-    extern __shared__ float fs_rows[];            // [R][pitch] alphas * mask
-    __shared__ int lens[8], nfires[8];
-    const int pitch = T | 1;
+    extern __shared__ __attribute__((aligned(16))) float fs_rows[];       // [R][pitch] alphas * mask -> integrals
+    __shared__ int lens[8], wtot[4];
+    const int pitch = scan_pitch(T), T16 = (T + 15) & ~15;
+    float* thr_rows = fs_rows + (size_t)R * pitch;                        // [R][pitch] per-frame thresholds
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * R;
     const int nrows = min(R, B - b0);
@@ -169,11 +173,15 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
         const size_t base = (size_t)(b0 + r) * T;
         const int n_r = attn_mask ? 0 : min(lengths[b0 + r], T);
         int c = 0;
-        for (int t = tid; t < T; t += 256) {
-            const float a = alphas[base + t];
-            const bool valid = attn_mask ? (attn_mask[base + t] != 0) : (t < n_r);
-            fs_rows[r * pitch + t] = valid ? a : a * 0.0f;     // alphas * attn_mask (keeps NaN/inf of the product)
-            c += valid ? 1 : 0;
+        for (int t = tid; t < T16; t += 256) {
+            float v = 0.0f;
+            if (t < T) {
+                const float a = alphas[base + t];
+                const bool valid = attn_mask ? (attn_mask[base + t] != 0) : (t < n_r);
+                v = valid ? a : a * 0.0f;                  // alphas * attn_mask (keeps NaN/inf of the product)
+                c += valid ? 1 : 0;
+            }
+            fs_rows[r * pitch + t] = v;
         }
         if (attn_mask) {
             c = wave_sum(c);
@@ -183,57 +191,45 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
         }
     }
     __syncthreads();
-    // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r
-    if (tid < nrows) {
-        const int b = b0 + tid;
-        const int n = lens[tid];
-        const float* row = fs_rows + tid * pitch;
-        float cur = 0.0f;
-        int nf = 0;
-        for (int t0 = 0; t0 < T; t0 += 16) {
-            float a[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = (t0 + k < T) ? row[t0 + k] : 0.0f;
-            // per-frame threshold, computed off the dependent chain: 1 normally, -inf at the last valid frame (forced
-            // fire), +inf past T -- the chain itself is add -> compare -> select
-            float thr[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int t = t0 + k;
-                thr[k] = (t >= T) ? __builtin_inff() : ((n == t + 1) ? -__builtin_inff() : 1.0f);
-            }
-            uint32_t fb = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                cur = __fadd_rn(cur, a[k]);
-                const bool fire = cur >= thr[k];
-                cur = fire ? __fsub_rn(cur, 1.0f) : cur;
-                fb |= (fire ? 1u : 0u) << k;
-            }
-            while (fb) {                                  // off the serial chain
-                const int t = t0 + __builtin_ctz(fb);
-                fb &= fb - 1;
-                if (nf < cap) {
-                    idx_out[(size_t)b * cap + nf] = t;
-                    if (mask_out) mask_out[(size_t)b * cap + nf] = 1;
-                    if (scores_gather) scores_gather[(size_t)b * cap + nf] = scores[(size_t)b * T + t];
-                }
-                ++nf;
-            }
-        }
-        nfires[tid] = nf;
-        if (counts) counts[b] = nf;
-        if (max_count) atomicMax(max_count, nf);
+    for (int r = 0; r < nrows; ++r) {
+        const int n = lens[r];
+        for (int t = tid; t < T16; t += 256) thr_rows[r * pitch + t] = (n == t + 1) ? -__builtin_inff() : 1.0f;
     }
     __syncthreads();
-    // phase 3 (all threads): pad slots
+    // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r
+    if (tid < nrows) cif_serial_chain<true>(fs_rows + tid * pitch, thr_rows + tid * pitch, 1.0f, T16 >> 4);
+    __syncthreads();
+    // phase 3 (all threads): fire_t = (I_t >= thr_t) for t < T; ascending positions by an exclusive scan over
+    // contiguous chunks of frames; pad slots carry index -1 == frame T-1
+    const int C = (T + 255) / 256;
     for (int r = 0; r < nrows; ++r) {
         const int b = b0 + r;
+        const float* ir = fs_rows + r * pitch;
+        const float* tr = thr_rows + r * pitch;
+        const int lo = min(tid * C, T), hi = min(lo + C, T);
+        int cnt = 0;
+        for (int t = lo; t < hi; ++t) cnt += (ir[t] >= tr[t]) ? 1 : 0;
+        int nf;
+        int slot = block_excl_scan_256(cnt, wtot, nf);
+        for (int t = lo; t < hi; ++t) {
+            if (ir[t] >= tr[t]) {
+                if (slot < cap) {
+                    idx_out[(size_t)b * cap + slot] = t;
+                    if (mask_out) mask_out[(size_t)b * cap + slot] = 1;
+                    if (scores_gather) scores_gather[(size_t)b * cap + slot] = scores[(size_t)b * T + t];
+                }
+                ++slot;
+            }
+        }
+        if (tid == 0) {
+            if (counts) counts[b] = nf;
+            if (max_count) atomicMax(max_count, nf);
+        }
         const float last_score = scores_gather ? scores[(size_t)b * T + (T - 1)] : 0.0f;
-        for (int j = nfires[r] + tid; j < cap; j += 256) {
+        for (int j = nf + tid; j < cap; j += 256) {
             idx_out[(size_t)b * cap + j] = -1;
             if (mask_out) mask_out[(size_t)b * cap + j] = 0;
-            if (scores_gather) scores_gather[(size_t)b * cap + j] = last_score;  // index -1 == frame T-1
+            if (scores_gather) scores_gather[(size_t)b * cap + j] = last_score;
         }
     }
 }
@@ -318,15 +314,15 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
     STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1, "star_cif_fire_scan: bad shape B=%d T=%d cap=%d", B, T, cap);
     STAR_REQUIRE(!scores_gather || scores, "star_cif_fire_scan: scores_gather requested without scores");
     STAR_REQUIRE(T <= 16384, "star_cif_fire_scan: T=%d exceeds the 16384-frame LDS row limit", T);
-    const int R = scan_rows_per_wg(T);
-    const size_t smem = (size_t)R * (T | 1) * 4;
+    const int R = scan_rows_per_wg(B, T);
+    const size_t smem = (size_t)R * scan_pitch(T) * 8;
     if (smem > 48 * 1024) {
         static bool done[64] = {};
         int dev = 0;
         hipGetDevice(&dev);
         if (!done[dev & 63]) {
             hipError_t e = hipFuncSetAttribute((const void*)cif_fire_scan_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
             if (e != hipSuccess) {
                 set_error("star_cif_fire_scan: cannot reserve LDS: %s", hipGetErrorString(e));
                 return STAR_ERR_LAUNCH;

@@ -17,88 +17,79 @@
 
 namespace star {
 
-static inline size_t cw_row_bytes(int T) { return (size_t)(2 * (T | 1) + ((T + 15) >> 4)) * 4; }
-static inline int cw_rows_per_wg(int T) {
-    int r = 4;
-    while (r > 1 && (size_t)r * cw_row_bytes(T) > 64 * 1024) r >>= 1;
+__host__ __device__ static inline int cw_pitch(int T) { return ((T + 15) & ~15) + 4; }
+static inline size_t cw_row_bytes(int T) { return (size_t)2 * cw_pitch(T) * 4; }
+static inline int cw_rows_per_wg(int B, int T) {
+    int r = 4;      // one utterance per workgroup unless the batch is huge (see scan_rows_per_wg in cif.hip)
+    while (r > 1 && ((size_t)r * cw_row_bytes(T) > 64 * 1024 || (B + r - 1) / r < 2048)) r >>= 1;
     return r;
 }
 
-// A workgroup owns R utterances.  (1) all 256 threads bring their alpha rows into LDS (coalesced); (2) lane r runs
-// the exact serial recurrence of row r from LDS in register blocks of 16 frames, keeping ONLY what is serial on the
-// dependent chain (integral, fire bit): it leaves 1 - I_before per frame, the fire bits and the fire count before
-// every block in LDS and writes the fire positions; (3) all threads turn that into the per-frame records
-// {cur, rem, segment/fire bits} in parallel (coalesced 16-byte stores).
+// A workgroup owns R utterances.  (1) all 256 threads bring their alpha rows into LDS twice (coalesced): one copy is
+// kept, the other is the work row of the recurrence; (2) lane r runs cif_serial_chain() on work row r (4 instructions
+// per frame), which leaves the pre-fire integrals I_t there; (3) all threads turn {alpha, I} into fires, the integral
+// before every frame, the fire positions (order-preserving compaction by an exclusive scan over contiguous chunks)
+// and the per-frame records {cur, rem, segment/fire bits} in parallel.
 __global__ __launch_bounds__(256) void cif_weights_kernel(const float* __restrict__ alphas, float threshold, int B, int T,
                                                          int cap, int R, f32x4* __restrict__ w_out,
                                                          int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out,
                                                          int32_t* __restrict__ counts, int32_t* __restrict__ max_count) {
-    extern __shared__ float cw_smem[];
-    const int pitch = T | 1;
-    const int nblk = (T + 15) >> 4;
+    extern __shared__ __attribute__((aligned(16))) float cw_smem[];
+    __shared__ int wtot[4];
+    const int pitch = cw_pitch(T), T16 = (T + 15) & ~15;
     float* a_rows = cw_smem;                                  // [R][pitch] alphas
-    float* dc_rows = a_rows + R * pitch;                      // [R][pitch] 1 - integral before the frame
-    uint32_t* blk = (uint32_t*)(dc_rows + R * pitch);         // [R][nblk] fire bits (low 16) | fires before << 16
-    __shared__ int nfires[4];
+    float* i_rows = a_rows + R * pitch;                       // [R][pitch] alphas -> integral after the add
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * R;
     const int nrows = min(R, B - b0);
     for (int r = 0; r < nrows; ++r)
-        for (int t = tid; t < T; t += 256) a_rows[r * pitch + t] = alphas[(size_t)(b0 + r) * T + t];
-    __syncthreads();
-    if (tid < nrows) {
-        const int b = b0 + tid;
-        const float* row = a_rows + tid * pitch;
-        float* dcr = dc_rows + tid * pitch;
-        float integ = 0.0f;
-        int nfire = 0;
-        for (int t0 = 0; t0 < T; t0 += 16) {
-            float a[16], dcv[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = (t0 + k < T) ? row[t0 + k] : 0.0f;
-            uint32_t fb = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                dcv[k] = __fsub_rn(1.0f, integ);
-                integ = __fadd_rn(integ, a[k]);
-                const bool fire = integ >= ((t0 + k < T) ? threshold : __builtin_inff());
-                integ = fire ? __fsub_rn(integ, 1.0f) : integ;
-                fb |= (fire ? 1u : 0u) << k;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (t0 + k < T) dcr[t0 + k] = dcv[k];
-            blk[tid * nblk + (t0 >> 4)] = fb | ((uint32_t)nfire << 16);
-            while (fb) {                                  // fire positions, off the dependent chain
-                const int k = __builtin_ctz(fb);
-                fb &= fb - 1;
-                if (nfire < cap) {
-                    idx_out[(size_t)b * cap + nfire] = t0 + k;
-                    if (mask_out) mask_out[(size_t)b * cap + nfire] = 1;
-                }
-                ++nfire;
-            }
+        for (int t = tid; t < T16; t += 256) {
+            const float a = (t < T) ? alphas[(size_t)(b0 + r) * T + t] : 0.0f;
+            a_rows[r * pitch + t] = a;
+            i_rows[r * pitch + t] = a;
         }
-        nfires[tid] = nfire;
-        counts[b] = nfire;
-        if (max_count) atomicMax(max_count, nfire);
-    }
     __syncthreads();
+    if (tid < nrows) cif_serial_chain<false>(i_rows + tid * pitch, nullptr, threshold, T16 >> 4);
+    __syncthreads();
+    const int C = (T + 255) / 256;
     for (int r = 0; r < nrows; ++r) {
-        const size_t ob = (size_t)(b0 + r) * T;
-        for (int t = tid; t < T; t += 256) {
-            const uint32_t e = blk[r * nblk + (t >> 4)];
-            const int k = t & 15;
-            const bool fire = (e >> k) & 1u;
-            const int before = (int)(e >> 16) + __popc(e & ((1u << k) - 1u));
-            const float a = a_rows[r * pitch + t];
-            const float c = fire ? dc_rows[r * pitch + t] : a;
+        const int b = b0 + r;
+        const float* ar = a_rows + r * pitch;
+        const float* ir = i_rows + r * pitch;
+        const size_t ob = (size_t)b * T;
+        const int lo = min(tid * C, T), hi = min(lo + C, T);
+        int cnt = 0;
+        for (int t = lo; t < hi; ++t) cnt += (ir[t] >= threshold) ? 1 : 0;
+        int nfire;
+        int before = block_excl_scan_256(cnt, wtot, nfire);
+        for (int t = lo; t < hi; ++t) {
+            const float it = ir[t];
+            const bool fire = it >= threshold;
+            // the integral the frame started from: the previous frame's, less 1 if that one fired
+            float prev = 0.0f;
+            if (t > 0) {
+                const float ip = ir[t - 1];
+                prev = (ip >= threshold) ? __fsub_rn(ip, 1.0f) : ip;
+            }
+            const float a = ar[t];
+            const float c = fire ? __fsub_rn(1.0f, prev) : a;
             // one 16-byte record per frame: {cur, rem, (fires before t) << 1 | fired, 0}
             w_out[ob + t] = (f32x4){c, __fsub_rn(a, c), __int_as_float((before << 1) | (fire ? 1 : 0)), 0.f};
+            if (fire) {
+                if (before < cap) {
+                    idx_out[(size_t)b * cap + before] = t;
+                    if (mask_out) mask_out[(size_t)b * cap + before] = 1;
+                }
+                ++before;
+            }
         }
-        for (int j = nfires[r] + tid; j < cap; j += 256) {
-            idx_out[(size_t)(b0 + r) * cap + j] = -1;
-            if (mask_out) mask_out[(size_t)(b0 + r) * cap + j] = 0;
+        if (tid == 0) {
+            counts[b] = nfire;
+            if (max_count) atomicMax(max_count, nfire);
+        }
+        for (int j = nfire + tid; j < cap; j += 256) {
+            idx_out[(size_t)b * cap + j] = -1;
+            if (mask_out) mask_out[(size_t)b * cap + j] = 0;
         }
     }
 }
@@ -244,7 +235,7 @@ extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int
         }
     }
     STAR_REQUIRE(T <= 16384, "star_cif_weights: T=%d exceeds the 16384-frame LDS row limit", T);
-    const int R = cw_rows_per_wg(T);
+    const int R = cw_rows_per_wg(B, T);
     const size_t smem = (size_t)R * cw_row_bytes(T);
     STAR_REQUIRE(T < 32768, "star_cif_weights: T too large");
     if (smem > 48 * 1024) {

@@ -53,4 +53,69 @@ __device__ __forceinline__ float bf2f(__bf16 b) { return (float)b; }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// The serial integrate-and-fire chain of one utterance, run by ONE lane on a row resident in LDS (16-byte aligned,
+// length a multiple of 16, zero padded): I += a_t; fire = I >= thr_t; I -= 1 where fired.  Every instruction of the
+// lane's wave costs a full issue slot whatever the number of active lanes, so the loop holds only what is serial:
+// per frame add, subtract, compare, select; the row is OVERWRITTEN with the pre-fire integrals I_t (after the add),
+// from which all threads afterwards recover fires (I_t >= thr_t), positions and weights in parallel.
+// HAS_THR = false: the constant threshold thr_const for every frame (thr_row unused).
+template <bool HAS_THR>
+__device__ __forceinline__ void cif_serial_chain(float* row, const float* thr_row, float thr_const, int nblk16) {
+    float cur = 0.0f;
+    f32x4 a[4], th[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a[q] = *(const f32x4*)(row + 4 * q);
+        if constexpr (HAS_THR) th[q] = *(const f32x4*)(thr_row + 4 * q);
+        else th[q] = (f32x4){thr_const, thr_const, thr_const, thr_const};
+    }
+    for (int blk = 0; blk < nblk16; ++blk) {
+        // the next block's operands are requested before this block's chain starts
+        f32x4 an[4], tn[4];
+        const int nb = (blk + 1 < nblk16) ? blk + 1 : blk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            an[q] = *(const f32x4*)(row + 16 * nb + 4 * q);
+            if constexpr (HAS_THR) tn[q] = *(const f32x4*)(thr_row + 16 * nb + 4 * q);
+            else tn[q] = th[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cur = __fadd_rn(cur, a[q][j]);
+                a[q][j] = cur;
+                const float less = __fsub_rn(cur, 1.0f);
+                cur = (cur >= th[q][j]) ? less : cur;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(row + 16 * blk + 4 * q) = a[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = an[q]; th[q] = tn[q]; }
+    }
+}
+
+// exclusive scan of one int per thread over a 256-thread workgroup (wtot: 4 ints of LDS); `total` = workgroup sum
+__device__ __forceinline__ int block_excl_scan_256(int v, int* wtot, int& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    int base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = wtot[w];
+        if (w < wid) base += t;
+        all += t;
+    }
+    __syncthreads();
+    total = all;
+    return base + incl - v;
+}
+
 }  // namespace star
