@@ -192,29 +192,41 @@ __global__ __launch_bounds__(256) void cif_aggregate_bwd_kernel(const T* __restr
     }
 }
 
-// d alpha_u = (fire_u ? drem_u : dcur_u) + sum_{t > u, fire_t} (drem_t - dcur_t): reverse scan, one wave per utterance
-__global__ __launch_bounds__(64) void cif_dalpha_kernel(const float* __restrict__ dcur, const float* __restrict__ drem,
-                                                       const f32x4* __restrict__ w, int Tn,
-                                                       float* __restrict__ dalphas) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    float carry = 0.f;      // sum over firing frames beyond the current chunk
-    const int nchunks = (Tn + 63) / 64;
-    for (int cidx = nchunks - 1; cidx >= 0; --cidx) {
-        const int t = cidx * 64 + lane;
-        const bool ok = t < Tn;
-        const size_t o = (size_t)b * Tn + (ok ? t : 0);
-        const bool fire = ok && (__float_as_int(w[o][2]) & 1);
-        const float dc = ok ? dcur[o] : 0.f, dr = ok ? drem[o] : 0.f;
-        const float v = fire ? (dr - dc) : 0.f;
-        // inclusive suffix sum over the lanes (lane 63 = latest frame of the chunk)
-        float incl = v;
+// d alpha_u = (fire_u ? drem_u : dcur_u) + sum_{t > u, fire_t} (drem_t - dcur_t): a suffix sum per utterance.  One
+// 256-thread workgroup per utterance, every thread owns a contiguous chunk of frames (all its loads in flight at once),
+// the chunk totals go through an exclusive suffix scan over the workgroup (fixed order: reproducible).
+__global__ __launch_bounds__(256) void cif_dalpha_kernel(const float* __restrict__ dcur, const float* __restrict__ drem,
+                                                        const f32x4* __restrict__ w, int Tn,
+                                                        float* __restrict__ dalphas) {
+    __shared__ float wtot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int C = (Tn + 255) / 256;
+    const int lo = min(tid * C, Tn), hi = min(lo + C, Tn);
+    const size_t base = (size_t)b * Tn;
+    // pass 1: the chunk's total of (drem - dcur) over firing frames
+    float tot = 0.f;
+    for (int t = hi - 1; t >= lo; --t) {
+        const bool fire = __float_as_int(w[base + t][2]) & 1;
+        tot += fire ? (drem[base + t] - dcur[base + t]) : 0.f;
+    }
+    // exclusive suffix sum of the chunk totals: lanes, then waves (later chunks = higher thread ids)
+    float incl = tot;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float n = __shfl_down(incl, off, 64);
-            if (lane + off < 64) incl += n;
-        }
-        if (ok) dalphas[o] = (fire ? dr : dc) + (incl - v) + carry;
-        carry += __shfl(incl, 0, 64);
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += n;
+    }
+    if (lane == 0) wtot[wid] = incl;
+    __syncthreads();
+    float after = incl - tot;
+    for (int x = 3; x > wid; --x) after += wtot[x];
+    // pass 2: walk the chunk backwards (the values are in L1/L2 now)
+    float run = after;
+    for (int t = hi - 1; t >= lo; --t) {
+        const bool fire = __float_as_int(w[base + t][2]) & 1;
+        const float dc = dcur[base + t], dr = drem[base + t];
+        dalphas[base + t] = (fire ? dr : dc) + run;
+        run += fire ? (dr - dc) : 0.f;
     }
 }
 
@@ -309,7 +321,7 @@ extern "C" int star_cif_aggregate_bwd(const void* dout, const void* s, int dtype
         else STAR_CIF_BWD(float, 1);
     }
 #undef STAR_CIF_BWD
-    hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(64), 0, st, (const float*)dcur, (const float*)drem,
+    hipLaunchKernelGGL(cif_dalpha_kernel, dim3(B), dim3(256), 0, st, (const float*)dcur, (const float*)drem,
                        (const f32x4*)weights, T, dalphas);
     STAR_LAUNCH_CHECK("star_cif_aggregate_bwd");
     return STAR_OK;
