@@ -429,7 +429,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         ep_store_nrows(W, p.GT, p.ldgt, n0 + wcol0, m0 + wrow0, p.N, lane);
-        if (n0 + wcol0 < p.N) {
+        if (p.G && n0 + wcol0 < p.N) {      // G (row-major) only feeds the dX GEMM: skipped when dX is not wanted
             __bf16* gdst = p.G + (int64_t)(m0 + wrow0 + (lane & 15)) * p.N + n0 + wcol0 + 8 * (lane >> 4);
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
@@ -822,7 +822,7 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     p.b1 = b1;
     p.w2 = w2;
     p.ds = dscores;
-    p.G = G;
+    p.G = dx ? G : nullptr;
     p.GT = GT;
     p.ldgt = Rpad;
     p.colpart = colpart;
