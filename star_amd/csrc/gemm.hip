@@ -623,11 +623,21 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
         // dw1: sum of the split-K slabs, 4 floats per thread
         const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
         if (i < dd) {
+            // four slabs per round: their loads are independent and in flight together (a rolled loop waits for
+            // every slab in turn); the summation order stays fixed
             f32x4 s = *(const f32x4*)(slab + i);
-            for (int k = 1; k < splits; ++k) {
-                const f32x4 v = *(const f32x4*)(slab + (int64_t)k * dd + i);
-                s += v;
+            int k = 1;
+            for (; k + 3 < splits; k += 4) {
+                const f32x4 v0 = *(const f32x4*)(slab + (int64_t)(k + 0) * dd + i);
+                const f32x4 v1 = *(const f32x4*)(slab + (int64_t)(k + 1) * dd + i);
+                const f32x4 v2 = *(const f32x4*)(slab + (int64_t)(k + 2) * dd + i);
+                const f32x4 v3 = *(const f32x4*)(slab + (int64_t)(k + 3) * dd + i);
+                s += v0;
+                s += v1;
+                s += v2;
+                s += v3;
             }
+            for (; k < splits; ++k) s += *(const f32x4*)(slab + (int64_t)k * dd + i);
             *(f32x4*)(dw1 + i) = s;
         }
         return;
@@ -639,17 +649,30 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
     const int col = cb * 64 + tx;                  // 0 .. 2d-1
     const int which = col / d, c = col % d;
     float a = 0.f;
-    for (int t = ty; t < nbm; t += 4) a += colpart[((int64_t)which * nbm + t) * d + c];
+    {
+        const float* cp = colpart + (int64_t)which * nbm * d + c;
+        int t = ty;
+        for (; t + 12 < nbm; t += 16) {
+            const float v0 = cp[(int64_t)(t + 0) * d], v1 = cp[(int64_t)(t + 4) * d];
+            const float v2 = cp[(int64_t)(t + 8) * d], v3 = cp[(int64_t)(t + 12) * d];
+            a += v0;
+            a += v1;
+            a += v2;
+            a += v3;
+        }
+        for (; t < nbm; t += 4) a += cp[(int64_t)t * d];
+    }
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0) {
         const float sum = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
         (which ? db1 : dw2)[c] = sum;
     }
-    if (cb == 0 && threadIdx.x == 0) {
+    if (cb == 0 && ty == 1) {                      // db2: one wave, lane-strided partial sums, then a fixed tree
         float s2 = 0.f;
-        for (int t = 0; t < nbm; ++t) s2 += colpart[(int64_t)2 * nbm * d + t];
-        db2[0] = s2;
+        for (int t = tx; t < nbm; t += 64) s2 += colpart[(int64_t)2 * nbm * d + t];
+        s2 = wave_sum(s2);
+        if (tx == 0) db2[0] = s2;
     }
 }
 
