@@ -495,7 +495,7 @@ class _XAttn(torch.autograd.Function):
         if per_head:
             # [B,h,K] view made by share_bias(): the same [B,K] logits for every head (stride 0 over heads); the
             # gradient then leaves as the per-head partials and share_bias() reduces all layers in one launch
-            if bias.shape[1] != h or bias.stride(1) != 0:
+            if bias.shape[1] != h or (h > 1 and bias.stride(1) != 0):
                 raise ValueError("xattn: a 3-d bias must be a [B,h,K] broadcast of [B,K] logits (see share_bias)")
             bias = bias[:, 0, :]
         bias_f = None if bias is None else bias.detach().to(torch.float32).contiguous()

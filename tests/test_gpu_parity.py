@@ -385,7 +385,7 @@ def test_xattn_random_vs_oracle(ops, B, h, L, K, hd, ilk):
     close(dsc, scr.grad, "dscores")
 
 
-@pytest.mark.parametrize("B,h,L,K,hd,nl", [(3, 4, 50, 90, 64, 3), (24, 8, 64, 140, 128, 2)])
+@pytest.mark.parametrize("B,h,L,K,hd,nl", [(3, 4, 50, 90, 64, 3), (24, 8, 64, 140, 128, 2), (5, 1, 20, 33, 64, 2)])
 def test_shared_scorer_logits_grad(ops, B, h, L, K, hd, nl):
     """share_scorer_logits: nl layers fed from one logits tensor; gradient = the per-layer path's (one launch sums
     the [B,h,K] partials of all layers instead of nl head reductions + autograd adds)."""
