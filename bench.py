@@ -129,10 +129,19 @@ def main():
     params = list(scorer.parameters())
     grad_targets = params + [inp.x, inp.s] + inp.qs
     allreduce = sd.FlatGradAllReduce(params)
+    if world > 1:
+        # the scorer gradients live in the flat all-reduce buffer: no copies around the collective
+        allreduce.attach()
+        grad_targets = [inp.x, inp.s] + inp.qs
 
-    def step():
+    def reset_grads():
         for t in grad_targets:
             t.grad = None
+        if world > 1:
+            allreduce.zero()
+
+    def step():
+        reset_grads()
         nugget_step_asr(scorer, inp, rate)
 
     # ---- eager warm-up (also fills the per-rate caches and the allocator), then graph capture
@@ -146,9 +155,10 @@ def main():
     graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
-        for t in grad_targets:
-            t.grad = None
+        reset_grads()
         with torch.cuda.graph(graph):
+            if world > 1:
+                allreduce.zero()               # part of the replayed step: backward accumulates into the buffer
             nugget_step_asr(scorer, inp, rate)
 
     def run_step():

@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -32,9 +33,14 @@ def _worker(rank, world, port, tmp):
     data = torch.load(os.path.join(tmp, "data.pt"))
     mine = sd.shard(list(range(len(data["lengths"]))), rank, world)
     params = [torch.nn.Parameter(p.clone()) for p in data["params"]]
+    ar = sd.FlatGradAllReduce(params)
+    if data.get("attach"):
+        ar.attach()            # gradients accumulate straight into the flat buffer
+        ar.zero()
     loss = _scorer_grads(data["x"][mine], [data["lengths"][i] for i in mine], 4, params)
     loss.backward()
-    ar = sd.FlatGradAllReduce(params)
+    if data.get("attach"):
+        assert all(p.grad.data_ptr() >= ar.flat.data_ptr() for p in params) and ar._still_attached()
     ar(world)
     sd.barrier()
     if rank == 0:
@@ -42,14 +48,15 @@ def _worker(rank, world, port, tmp):
     torch.distributed.destroy_process_group()
 
 
-def test_sharded_allreduce_matches_single_process(tmp_path):
+@pytest.mark.parametrize("attach", [False, True])
+def test_sharded_allreduce_matches_single_process(tmp_path, attach):
     torch.manual_seed(0)
     d, t, b = 16, 40, 6
     lengths = [40, 33, 21, 40, 8, 17]
     x = torch.randn(b, t, d)
     params = [torch.randn(d, d) * 0.2, torch.randn(d) * 0.1, torch.randn(1, d) * 0.2, torch.randn(1) * 0.1]
-    torch.save({"x": x, "lengths": lengths, "params": params}, tmp_path / "data.pt")
-    port = 29611 + os.getpid() % 200
+    torch.save({"x": x, "lengths": lengths, "params": params, "attach": attach}, tmp_path / "data.pt")
+    port = 29611 + os.getpid() % 200 + (300 if attach else 0)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = torch.load(tmp_path / "grads.pt")
     full = [torch.nn.Parameter(p.clone()) for p in params]
