@@ -478,6 +478,15 @@ def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale):
     return s
 
 
+def _empty_same_strides(t):
+    e = torch.empty_like(t)
+    if e.stride() == t.stride():
+        return e
+    if any(st == 0 and n > 1 for st, n in zip(t.stride(), t.shape)):
+        raise _lib.StarNuggetError("xattn: expanded (stride-0) q / k / v are not supported; call .contiguous() first")
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
 class _XAttn(torch.autograd.Function):
     """softmax(QK^T*scale + ILK + bias) V with d(bias) = sum_{h,i} dS (my_transformer.py:535-603)."""
 
@@ -531,11 +540,9 @@ class _XAttn(torch.autograd.Function):
         else:
             go = torch.empty_like(o)
             go.copy_(g)
-        dq = torch.empty_like(qb)
-        dk = torch.empty_like(kb)
-        dv = torch.empty_like(vb)
-        if dq.stride() != qb.stride() or dk.stride() != kb.stride() or dv.stride() != vb.stride():
-            raise _lib.StarNuggetError("xattn backward: gradient buffers do not share the input strides")
+        # the kernels write dQ / dK / dV with the strides of Q / K / V.  Views with gaps (K and V are the two halves of
+        # one c_attn output in MyGPT2Attention.forward, my_transformer.py:500-508) are not reproduced by empty_like.
+        dq, dk, dv = _empty_same_strides(qb), _empty_same_strides(kb), _empty_same_strides(vb)
         delta = torch.empty((B, h, L), dtype=torch.float32, device=dev)
         dbias = part = None
         if bias_f is not None:

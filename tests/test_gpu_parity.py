@@ -465,6 +465,51 @@ def test_dropin_signatures(ops):
     np.testing.assert_allclose(p.cpu().numpy(), x["p"], rtol=5e-2, atol=5e-3)
 
 
+@pytest.mark.parametrize("ilk", [False, True])
+def test_cross_attention_module_vs_oracle(ops, ilk):
+    """Row a9: the whole cross-attention branch of MyGPT2Attention.forward (my_transformer.py:490-533) -- q_attn,
+    c_attn, split heads, score-biased core, merge heads, c_proj -- against the same arithmetic in fp32 with the
+    oracle's core, forward and parameter / input gradients."""
+    from star_amd.nugget import NuggetCrossAttention
+    torch.manual_seed(11)
+    d, h, B, L, K = 256, 4, 3, 20, 37
+    m = NuggetCrossAttention(d, h).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.05 if prm.dim() == 2 else 0.02))
+    x = torch.randn(B, L, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    enc = torch.randn(B, K, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    sc = torch.randn(B, K, device=DEV).requires_grad_()
+    klen = [K, K - 9, 5]
+    kmask = lmask(klen, K)
+    add = dev(((1.0 - kmask[:, None, None, :].astype(np.float32)) * np.finfo(np.float32).min))
+    gout = torch.randn(B, L, d, device=DEV).to(torch.bfloat16)
+    out = m(x, encoder_hidden_states=enc, encoder_attention_mask=add, scorer_logits=sc, limit_cross_attn=ilk)[0]
+    out.backward(gout)
+
+    # fp32 restatement on the same (bf16-valued) parameters and inputs
+    P = {n: t.detach().float().cpu().requires_grad_() for n, t in m.named_parameters()}
+    xr, er, sr = (t.detach().float().cpu().requires_grad_() for t in (x, enc, sc))
+    split = lambda t: t.view(t.shape[0], t.shape[1], h, d // h).permute(0, 2, 1, 3)
+    q = split(xr @ P["q_attn.weight"] + P["q_attn.bias"])
+    kv = er @ P["c_attn.weight"] + P["c_attn.bias"]
+    k, v = split(kv[..., :d]), split(kv[..., d:])
+    o_ref, _ = orc.xattn_core(q, k, v, torch.from_numpy(kmask), sr, ilk)
+    y = o_ref.permute(0, 2, 1, 3).reshape(B, L, d) @ P["c_proj.weight"] + P["c_proj.bias"]
+    (y * gout.float().cpu()).sum().backward()
+
+    def close(a, b, what, tol=3e-2):
+        a, b = a.detach().float().cpu().numpy(), b.detach().numpy()
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= tol * scale + 1e-6, f"{what}: max err {np.abs(a - b).max()} scale {scale}"
+    close(out, y, "output")
+    close(x.grad, xr.grad, "d hidden")
+    close(enc.grad, er.grad, "d encoder memory")
+    close(sc.grad, sr.grad, "d scorer_logits")
+    for n, t in m.named_parameters():
+        close(t.grad, P[n].grad, "d " + n)
+
+
 def test_cross_attention_kv_cache(ops):
     """Generation keeps the projected encoder K/V: the reference recomputes c_attn(memory) for every
     token (my_transformer.py:724-733); the cached path must give the same output and project the memory once."""
