@@ -552,6 +552,89 @@ def test_reference_style_composition_fp32(ops):
             close(t.grad, P[n].grad, "d " + n)
 
 
+def test_reference_style_composition_simul(ops):
+    """The simultaneous path composed as W2VSimulModel.lm_nugget_training does (w2v_simul.py:407-465), with the
+    torch lines a maintainer keeps (sigmoid, quantity loss, indexing with -1) next to the drop-in methods (resize,
+    apply_threshold_yield_nugget, add_nugget_type_embedding, gather, ILK cross-attention)."""
+    from star_amd.nugget import NuggetCrossAttention, NuggetOpsMixin, NuggetScorer, gather_nuggets
+    torch.manual_seed(23)
+    B, T, d, h, L = 3, 60, 256, 4, 9
+    lengths, tlen = [60, 44, 13], [7, 5, 2]
+
+    class Host(NuggetOpsMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.nugget_model = NuggetScorer(d)
+            self.crossattention = NuggetCrossAttention(d, h)
+
+    m = Host().to(DEV)
+    with torch.no_grad():
+        for prm in m.crossattention.parameters():
+            prm.copy_(torch.randn_like(prm) * (0.05 if prm.dim() == 2 else 0.02))
+    x = torch.randn(B, T, d, device=DEV)
+    x = (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True)
+    sem = torch.randn(B, T, d, device=DEV, requires_grad=True)
+    hid = torch.randn(B, L, d, device=DEV)
+    gout = torch.randn(B, L, d, device=DEV)
+    mask = dev(lmask(lengths, T))
+    tl = torch.tensor(tlen, device=DEV)
+
+    scores = m.nugget_model(x.detach()).squeeze(-1)                                       # :410-411
+    alphas = torch.sigmoid(scores) * mask                                                 # :419
+    qloss = ((alphas.sum(1) / 1.0 - tl) ** 2).mean()                                      # :420-424
+    resized = m.resize(alphas, tl)                                                        # :425
+    nmask, nidx, _ = m.apply_threshold_yield_nugget(resized, mask)                        # :426
+    nscores = scores[torch.arange(B, device=DEV).unsqueeze(1), nidx]                      # :427 (-1 = last frame)
+    table, pos = m.add_nugget_type_embedding(x, nidx, nmask)                              # :431
+    mem = gather_nuggets(sem, nidx)                                                       # :446-447
+    add = (1.0 - nmask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    out = m.crossattention(hid, encoder_hidden_states=mem, encoder_attention_mask=add, scorer_logits=nscores,
+                           limit_cross_attn=True)[0]
+    ((out * gout).sum() + 0.01 * qloss).backward()                                        # :461
+
+    # oracle chain on the GPU's scores (index parity is asserted on scores of the same scorer implementation)
+    P = {n: t.detach().cpu().clone().requires_grad_() for n, t in m.named_parameters()}
+    s_leaf = scores.detach().cpu().clone().requires_grad_()
+    mk = torch.from_numpy(lmask(lengths, T))
+    a_ref = torch.sigmoid(s_leaf) * mk
+    q_ref = ((a_ref.sum(1) - torch.tensor(tlen)) ** 2).mean()
+    r_ref = orc.resize(a_ref.detach(), torch.tensor(tlen))
+    np.testing.assert_allclose(resized.detach().cpu().numpy(), r_ref.numpy(), rtol=2e-5, atol=1e-7)
+    f_mask, f_idx, _ = orc.fire_scan(resized.detach().cpu().numpy(), lmask(lengths, T), with_block_mask=False)
+    kf = nidx.shape[1]
+    np.testing.assert_array_equal(nidx.cpu().numpy(), f_idx[:, :kf])
+    np.testing.assert_array_equal(nmask.cpu().numpy(), f_mask[:, :kf])
+    it = torch.from_numpy(f_idx[:, :kf])
+    ns_ref = s_leaf[torch.arange(B).unsqueeze(1), it]
+    sem_r = sem.detach().cpu().clone().requires_grad_()
+    mem_r = orc.gather_rows(sem_r, it)
+    split = lambda t: t.view(t.shape[0], t.shape[1], h, d // h).permute(0, 2, 1, 3)
+    q = split(hid.cpu() @ P["crossattention.q_attn.weight"] + P["crossattention.q_attn.bias"])
+    kv = mem_r @ P["crossattention.c_attn.weight"] + P["crossattention.c_attn.bias"]
+    o_ref, _ = orc.xattn_core(q, split(kv[..., :d]), split(kv[..., d:]), torch.from_numpy(f_mask[:, :kf]), ns_ref, True)
+    y = o_ref.permute(0, 2, 1, 3).reshape(B, L, d) @ P["crossattention.c_proj.weight"] + P["crossattention.c_proj.bias"]
+    ((y * gout.cpu()).sum() + 0.01 * q_ref).backward()
+
+    def close(a, b, what, tol=3e-2):
+        a, b = a.detach().float().cpu().numpy(), b.detach().numpy()
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= tol * scale + 1e-6, f"{what}: max err {np.abs(a - b).max()} scale {scale}"
+    close(out, y, "output")
+    close(sem.grad, sem_r.grad, "d semantic states")
+    for n in ("q_attn", "c_attn", "c_proj"):
+        close(getattr(m.crossattention, n).weight.grad, P[f"crossattention.{n}.weight"].grad, "d " + n)
+    # the scorer gradients against torch's own backward through the scorer from the oracle's dscores
+    ds = s_leaf.grad.to(DEV)
+    ref_params = [t.detach().clone().requires_grad_() for t in m.nugget_model.parameters()]
+    w1, b1, w2, b2 = ref_params
+    s2 = (torch.relu(x @ w1.t() + b1) @ w2.t() + b2).squeeze(-1)
+    s2.backward(ds)
+    for (n, t), r in zip(m.nugget_model.named_parameters(), ref_params):
+        a, b = t.grad.detach().cpu().numpy(), r.grad.cpu().numpy()
+        bad = np.abs(a - b) > 3e-2 * np.abs(b).max() + 1e-6
+        assert bad.mean() <= 0.02, f"d nugget_model.{n}: {bad.mean():.3%} of the entries off"
+
+
 @pytest.mark.parametrize("ilk", [False, True])
 def test_cross_attention_module_vs_oracle(ops, ilk):
     """Row a9: the whole cross-attention branch of MyGPT2Attention.forward (my_transformer.py:490-533) -- q_attn,
