@@ -1,0 +1,60 @@
+"""Host-side mirror of the reference's operator interface (no GPU): module names, parameter / state_dict keys, and
+the error behaviour of the drop-in functions."""
+import pytest
+import torch
+
+import star_amd
+from star_amd.nugget import NuggetCrossAttention, NuggetOpsMixin, NuggetScorer, score_biased_attn
+
+
+def test_scorer_state_dict_matches_the_reference_sequential():
+    """nugget_model = nn.Sequential(nn.Linear(h,h), nn.ReLU(inplace=True), nn.Linear(h,1)) (w2v_asr.py:113-117): the
+    same keys and shapes, so checkpoints and the trainers' "nugget" optimizer grouping keep working."""
+    d = 32
+    ref = torch.nn.Sequential(torch.nn.Linear(d, d), torch.nn.ReLU(inplace=True), torch.nn.Linear(d, 1))
+    mine = NuggetScorer(d)
+    assert list(mine.state_dict().keys()) == list(ref.state_dict().keys()) == ["0.weight", "0.bias", "2.weight", "2.bias"]
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(mine.state_dict()[k], v)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.nugget_model = NuggetScorer(d)
+
+    names = [n for n, _ in Model().named_parameters()]
+    assert names == ["nugget_model.0.weight", "nugget_model.0.bias", "nugget_model.2.weight", "nugget_model.2.bias"]
+    assert all("nugget" in n for n in names)                       # wav2vec_trainer.py:385-387 groups by substring
+
+
+def test_cross_attention_parameter_names_and_conv1d_layout():
+    """GPT2Attention(is_cross_attention=True): q_attn, c_attn, c_proj as HF Conv1D (weight [in, out])."""
+    d = 48
+    m = NuggetCrossAttention(d, 4)
+    shapes = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    assert shapes == {"c_attn.weight": (d, 2 * d), "c_attn.bias": (2 * d,), "q_attn.weight": (d, d),
+                      "q_attn.bias": (d,), "c_proj.weight": (d, d), "c_proj.bias": (d,)}
+    with pytest.raises(ValueError):
+        NuggetCrossAttention(50, 4)                                # embed_dim must be divisible by num_heads
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 2, d))                                    # cross-attention needs encoder_hidden_states
+
+
+def test_error_behaviour_without_a_gpu():
+    q = torch.zeros(1, 2, 3, 64)
+    k = torch.zeros(1, 2, 5, 64)
+    with pytest.raises(NotImplementedError):
+        score_biased_attn(q, k, k, head_mask=torch.ones(2))
+    with pytest.raises(ValueError):
+        score_biased_attn(q, k, k, scorer_logits=torch.zeros(1, 6))      # more logits than keys
+    with pytest.raises(ValueError):
+        score_biased_attn(q, k, k, attention_mask=torch.zeros(1, 1, 1, 4))
+    with pytest.raises(star_amd.ops.StarDeviceError):
+        score_biased_attn(q, k, k)                                      # CPU tensors: there is no fallback path
+    with pytest.raises(NotImplementedError):
+        NuggetOpsMixin().resize(torch.zeros(1, 4), torch.ones(1), noise=0.1)
+    with pytest.raises(star_amd.ops.StarDeviceError):
+        star_amd.share_scorer_logits(torch.zeros(2, 5), 3, 4)
+    with pytest.raises(star_amd.ops.StarDeviceError):
+        star_amd.ops.type_embed_add(torch.zeros(2, 3, 8), torch.zeros(2, 3, dtype=torch.long), torch.zeros(2, 8))
