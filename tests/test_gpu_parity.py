@@ -953,3 +953,85 @@ def test_type_embed_random_vs_oracle(ops, B, T, d, dtype):
     tol = 1e-5 if dtype == torch.float32 else 1e-2          # d emb leaves in the weight's dtype
     ref_dw = wr.grad.numpy()
     np.testing.assert_allclose(wd.grad.float().cpu().numpy(), ref_dw, rtol=tol, atol=tol * np.abs(ref_dw).max())
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties(ops):
+    """configs[1] sizes (B32 x T1500 x d1024, rate 4, 8 heads, L128): too big for the oracle in seconds, so the path is
+    checked through size-independent properties -- exact scalings, orderings, counts, row sums, shift invariance."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(5)
+    B, T, d, h, L, rate = 32, 1500, 1024, 8, 128, 4
+    K = int(np.ceil(T / rate))
+    rng = np.random.default_rng(3)
+    lengths = [T] + [int(v) for v in rng.integers(T // 3, T + 1, size=B - 1)]
+    len_dev = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    x = torch.randn(B, T, d, device=DEV)
+    x = ((x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True)).to(torch.bfloat16)
+
+    # scorer: doubling w2 and b2 doubles every score exactly (a power-of-two scaling commutes with every rounding)
+    sc = NuggetScorer(d).to(DEV)
+    with torch.no_grad():
+        s1 = sc(x).squeeze(-1).float()
+        sc[2].weight.mul_(2.0)
+        sc[2].bias.mul_(2.0)
+        s2 = sc(x).squeeze(-1).float()
+    assert torch.equal(s2, 2.0 * s1)
+
+    # select: counts, ordering, type table, idempotence
+    nmask, idx, sg, table, pos = ops.topk_select(s1, lengths=len_dev, rate=rate, K=K)
+    kb = orc.nugget_counts(np.asarray(lengths), rate)
+    np.testing.assert_array_equal(nmask.sum(1).cpu().numpy(), kb)
+    np.testing.assert_array_equal(table.sum(1).cpu().numpy(), kb)
+    idx_c, nm_c = idx.cpu().numpy(), nmask.cpu().numpy().astype(bool)
+    for b in range(B):
+        kept = idx_c[b, nm_c[b]]
+        assert (np.diff(kept) > 0).all() and kept[-1] == lengths[b] - 1          # ascending, last valid frame kept
+        assert (np.diff(idx_c[b, ~nm_c[b]]) > 0).all()                          # pad group ascending too
+    assert torch.equal(pos[nmask.bool()], idx[nmask.bool()]) and (pos[~nmask.bool()] == -1).all()
+    assert torch.equal(sg, s1.gather(1, idx))
+    again = ops.topk_select(s1, lengths=len_dev, rate=rate, K=K)
+    assert all(torch.equal(a, b) for a, b in zip((nmask, idx, sg, table, pos), again))
+
+    # gather: rows are copies; the backward of ones counts how often a frame was taken
+    s_rep = torch.randn(B, T, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    mem = ops.gather_rows(s_rep, idx)
+    probe = rng.integers(0, K, size=64)
+    for b, j in zip(rng.integers(0, B, size=64), probe):
+        assert torch.equal(mem[b, j], s_rep[b, idx[b, j]])
+    mem.backward(torch.ones_like(mem))
+    counts = torch.zeros(B, T, device=DEV).scatter_add_(1, idx, torch.ones(B, K, device=DEV))
+    assert torch.equal(s_rep.grad[..., 0].float(), counts) and torch.equal(s_rep.grad[..., -1].float(), counts)
+
+    # attention core: exact linearity in V, P rows sum to 1, shift invariance in the bias, sum_j dbias = 0
+    key_len = torch.from_numpy(kb.astype(np.int32)).to(DEV)
+    q = torch.randn(B, h, L, d // h, device=DEV).to(torch.bfloat16)
+    kk = mem.detach().view(B, K, h, d // h).permute(0, 2, 1, 3)
+    vv = torch.randn(B, K, h, d // h, device=DEV).to(torch.bfloat16).permute(0, 2, 1, 3)
+    bias = sg.detach().clone().requires_grad_()
+    o1, p1 = ops.xattn(q, kk, vv, bias=bias, key_len=key_len, need_probs=True)
+    o2, _ = ops.xattn(q, kk, vv * 2, bias=bias, key_len=key_len)
+    assert torch.equal(o2, o1 * 2)
+    rows = p1.sum(-1)
+    assert (rows - 1).abs().max() < 1e-4
+    dead = torch.arange(K, device=DEV)[None, :] >= key_len[:, None]
+    assert (p1.permute(0, 3, 1, 2)[dead] == 0).all()                               # masked keys: exact zeros
+    o3, _ = ops.xattn(q, kk, vv, bias=bias.detach() + 3.0, key_len=key_len)
+    assert (o3.float() - o1.float()).abs().max() <= 2e-2 * o1.float().abs().max()
+    o1.backward(torch.randn_like(o1))
+    live = ~dead
+    tot = (bias.grad * live).sum(1).abs()
+    assert (tot <= 2e-3 * (bias.grad * live).abs().sum(1) + 1e-6).all()            # softmax is shift invariant
+    assert (bias.grad[dead] == 0).all()
+
+    # fire scan: ascending positions, forced fire at the last valid frame, count == oracle on a few rows
+    alphas = torch.rand(B, T, device=DEV) * 0.15
+    fidx, fmask, fcounts, mx, _ = ops.cif_fire_scan(alphas, lengths=len_dev, cap=T)
+    fi, fc = fidx.cpu().numpy(), fcounts.cpu().numpy()
+    for b in range(B):
+        f = fi[b, :fc[b]]
+        assert (np.diff(f) > 0).all() and (lengths[b] - 1) in f and (fi[b, fc[b]:] == -1).all()
+    sub = [0, 7, 31]
+    o_mask, o_idx, _ = orc.fire_scan(alphas[sub].cpu().numpy(), lmask([lengths[i] for i in sub], T), with_block_mask=False)
+    for r, b in enumerate(sub):
+        np.testing.assert_array_equal(fi[b, :fc[b]], o_idx[r, :o_mask[r].sum()])
