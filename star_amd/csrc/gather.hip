@@ -261,6 +261,57 @@ extern "C" int star_gather_rows_fwd(const void* src, const int64_t* idx, void* d
     return STAR_OK;
 }
 
+// d = 1 (the score gather of w2v_asr.py:244 / w2v_simul.py:427): one workgroup per utterance builds the whole dense
+// row in LDS.  Targets hit once take their value directly; a target hit several times (pad slots all address frame
+// T-1) is summed by the thread of its first slot in ascending slot order (fp32, one rounding at the end) -- the same
+// result as the tiled kernel above, which spends a wave per frame on one element when d = 1.
+constexpr int GS_MAX = 6144;       // T and K limit of the LDS-resident variant (120 KB of LDS at the limit)
+template <typename T_ELEM>
+__global__ __launch_bounds__(256) void scatter_scalar_bwd_kernel(const T_ELEM* __restrict__ ddst,
+                                                                 const int64_t* __restrict__ idx,
+                                                                 T_ELEM* __restrict__ dsrc, int T, int K) {
+    extern __shared__ int gs_smem[];
+    int* cnt = gs_smem;                        // [T]
+    int* first = cnt + T;                      // [T]
+    float* acc = (float*)(first + T);          // [T]
+    int* tj = (int*)(acc + T);                 // [K] target frame of slot j (-1: out of range)
+    float* gj = (float*)(tj + K);              // [K]
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int t = tid; t < T; t += 256) {
+        cnt[t] = 0;
+        first[t] = 0x7FFFFFFF;
+        acc[t] = 0.f;
+    }
+    for (int j = tid; j < K; j += 256) {
+        int64_t t = idx[(size_t)b * K + j];
+        if (t < 0) t += T;
+        tj[j] = (t >= 0 && t < T) ? (int)t : -1;
+        gj[j] = (float)ddst[(size_t)b * K + j];
+    }
+    __syncthreads();
+    for (int j = tid; j < K; j += 256) {
+        const int t = tj[j];
+        if (t >= 0) {
+            atomicAdd(&cnt[t], 1);
+            atomicMin(&first[t], j);
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < K; j += 256) {
+        const int t = tj[j];
+        if (t < 0) continue;
+        if (cnt[t] == 1) {
+            acc[t] = gj[j];
+        } else if (first[t] == j) {
+            float sum = 0.f;
+            for (int jj = j; jj < K; ++jj) sum += (tj[jj] == t) ? gj[jj] : 0.f;
+            acc[t] = sum;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) dsrc[(size_t)b * T + t] = (T_ELEM)acc[t];
+}
+
 extern "C" int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* dsrc, int B, int T, int K, int d,
                                     int dtype, void* stream) {
     using namespace star;
@@ -268,10 +319,37 @@ extern "C" int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* 
     STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && d >= 1, "star_gather_rows_bwd: bad shape B=%d T=%d K=%d d=%d", B, T, K, d);
     STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_gather_rows_bwd: bad dtype %d", dtype);
     STAR_REQUIRE(B <= 65535, "star_gather_rows_bwd: B=%d exceeds grid.y", B);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 1 && T <= GS_MAX && K <= GS_MAX) {
+        const size_t smem = ((size_t)3 * T + (size_t)2 * K) * 4;
+        if (smem > 48 * 1024) {
+            static bool done[2][64] = {};
+            int dev = 0;
+            hipGetDevice(&dev);
+            const int w = dtype == STAR_DT_BF16 ? 0 : 1;
+            if (!done[w][dev & 63]) {
+                const void* fn = w == 0 ? (const void*)scatter_scalar_bwd_kernel<__bf16>
+                                        : (const void*)scatter_scalar_bwd_kernel<float>;
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * GS_MAX + 2 * GS_MAX) * 4) !=
+                    hipSuccess) {
+                    set_error("star_gather_rows_bwd: cannot reserve LDS");
+                    return STAR_ERR_LAUNCH;
+                }
+                done[w][dev & 63] = true;
+            }
+        }
+        if (dtype == STAR_DT_BF16)
+            hipLaunchKernelGGL(scatter_scalar_bwd_kernel<__bf16>, dim3(B), dim3(256), smem, st, (const __bf16*)ddst, idx,
+                               (__bf16*)dsrc, T, K);
+        else
+            hipLaunchKernelGGL(scatter_scalar_bwd_kernel<float>, dim3(B), dim3(256), smem, st, (const float*)ddst, idx,
+                               (float*)dsrc, T, K);
+        STAR_LAUNCH_CHECK("star_gather_rows_bwd");
+        return STAR_OK;
+    }
     dim3 grid(cdiv(T, GB_TILE), B), block(256);
     const int esz = dtype == STAR_DT_BF16 ? 2 : 4;
     const bool v4 = (d % 4 == 0) && (((uintptr_t)ddst | (uintptr_t)dsrc) % (4 * esz) == 0);
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == STAR_DT_BF16) {
         if (v4)
             hipLaunchKernelGGL((gather_rows_bwd_kernel<__bf16, 4>), grid, block, 0, st, (const __bf16*)ddst, idx,

@@ -138,6 +138,25 @@ def test_gather_scores_negative_index(ops):
     np.testing.assert_allclose(scores.grad.cpu().numpy(), acc.numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,T,K,dtype", [(32, 1500, 375, torch.float32), (5, 700, 900, torch.float32),
+                                         (3, 6144, 50, torch.float32), (2, 7000, 40, torch.float32)])
+def test_gather_scores_backward_random_duplicates(ops, B, T, K, dtype):
+    """Score gather backward (d = 1) with many duplicates and -1 pads: equal to an fp32 scatter-add in slot order
+    (the LDS-resident variant up to T, K = 6144; the tiled kernel beyond)."""
+    g = torch.Generator().manual_seed(T + K)
+    scores = torch.randn(B, T, generator=g).to(dtype).to(DEV).requires_grad_()
+    idx = torch.randint(-1, T, (B, K), generator=g)
+    idx[:, K // 2:] = torch.where(torch.rand(B, K - K // 2, generator=g) < 0.5, torch.tensor(-1), idx[:, K // 2:])
+    w = torch.randn(B, K, generator=g).to(dtype)
+    out = ops.gather_rows(scores, idx.to(DEV))
+    out.backward(w.to(DEV))
+    acc = torch.zeros(B, T, dtype=torch.float32)
+    acc.scatter_add_(1, torch.where(idx < 0, idx + T, idx), w.float())
+    ref = acc.to(dtype).float().numpy()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(scores.grad.float().cpu().numpy(), ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
 # ------------------------------------------------------------------------------------------------ CIF
 @pytest.mark.parametrize("name", ["cif_plain", "cif_fixup", "cif_ragged"])
 def test_cif_golden(ops, name):
