@@ -217,8 +217,11 @@ class NuggetCrossAttention(nn.Module):
     Parameters: q_attn, c_attn, c_proj (Conv1D layout) as in GPT2Attention(is_cross_attention=True)."""
 
     def __init__(self, hidden_size: int, num_heads: int, layer_idx: int = 0, scale_attn_weights: bool = True,
-                 scale_attn_by_inverse_layer_idx: bool = False, resid_pdrop: float = 0.0):
+                 scale_attn_by_inverse_layer_idx: bool = False, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0):
         super().__init__()
+        # dropout on the attention probabilities (GPT2Config.attn_pdrop, 0.1 by default) is not implemented inside the
+        # fused core: refuse it in training rather than train silently without it
+        self.attn_pdrop = float(attn_pdrop)
         if hidden_size % num_heads:
             raise ValueError("`embed_dim` must be divisible by num_heads")
         self.embed_dim, self.num_heads, self.head_dim = hidden_size, num_heads, hidden_size // num_heads
@@ -268,6 +271,9 @@ class NuggetCrossAttention(nn.Module):
                 scorer_logits=None, limit_cross_attn=False):
         if encoder_hidden_states is None:
             raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
+        if self.training and self.attn_pdrop > 0.0:
+            raise NotImplementedError(f"attn_pdrop = {self.attn_pdrop}: attention-probability dropout is not implemented "
+                                      "in the fused core; build the decoder config with attn_pdrop = 0")
         query = self._split_heads(self.q_attn(hidden_states))
         key, value = self._encoder_kv(encoder_hidden_states)
         if layer_past is not None:

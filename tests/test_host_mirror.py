@@ -39,6 +39,9 @@ def test_cross_attention_parameter_names_and_conv1d_layout():
         NuggetCrossAttention(50, 4)                                # embed_dim must be divisible by num_heads
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, d))                                    # cross-attention needs encoder_hidden_states
+    drop = NuggetCrossAttention(d, 4, attn_pdrop=0.1)
+    with pytest.raises(NotImplementedError):                       # refused loudly in training, fine in eval
+        drop(torch.zeros(1, 2, d), encoder_hidden_states=torch.zeros(1, 3, d))
 
 
 def test_error_behaviour_without_a_gpu():
