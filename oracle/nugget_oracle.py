@@ -24,7 +24,6 @@ Reference lines restated (all paths relative to the reference checkout):
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch

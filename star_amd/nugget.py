@@ -22,8 +22,7 @@ Everything runs in the HIP kernels of libstar_nugget.so; there is no CPU path.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 from torch import nn
