@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
     }
 }
 
-// Fused short-target backward (L <= 128, HD = 64 or 128, B*h large enough to fill the chip on its own): dQ, dK, dV
+// Fused short-target backward (L <= 128, HD = 64 or 128; all but tiny batches with very long memories): dQ, dK, dV
 // and the bias-gradient partials of one (batch, head) from ONE pass over K / V.  The two products want opposite
 // ownerships (dK/dV: a wave owns keys and sees every query; dQ: a wave owns queries and sees every key), so the keys
 // are walked in rounds of 128 = one 16-key group per wave:
@@ -1712,7 +1712,11 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
     if constexpr (HD == 64 || HD == 128) {
         static const char* dkv_force0 = getenv("STAR_XA_DKV");
         const bool fused_ok = s->L <= BwdFused<HD>::QROWS && !dq_force && !dkv_force0;
-        const bool want = bwd_force ? (bwd_force[0] == 'f') : ((int64_t)s->B * s->h >= 192);
+        // measured at configs[1]'s shape from B = 1 to 128: the fused kernel wins at every batch size (K = 375: 3 rounds);
+        // only few (batch, head) pairs with MANY key rounds are left to the split pair, whose dK/dV kernel spreads
+        // the key groups of one pair over several workgroups
+        const int64_t bh_f = (int64_t)s->B * s->h;
+        const bool want = bwd_force ? (bwd_force[0] == 'f') : (bh_f >= 32 || s->Kn <= 512);
         if (fused_ok && want) {
             const int smem_f = BwdFused<HD>::BYTES;
             static bool done_fused[64] = {};

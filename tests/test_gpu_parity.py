@@ -1054,3 +1054,38 @@ def test_full_size_properties(ops):
     o_mask, o_idx, _ = orc.fire_scan(alphas[sub].cpu().numpy(), lmask([lengths[i] for i in sub], T), with_block_mask=False)
     for r, b in enumerate(sub):
         np.testing.assert_array_equal(fi[b, :fc[b]], o_idx[r, :o_mask[r].sum()])
+
+
+def test_xattn_split_backward_path_in_subprocess(ops, tmp_path):
+    """The dispatcher now sends almost every short-target shape to the fused backward; the split pair (ring dQ +
+    barrier-free dK/dV) stays the path for few (batch, head) pairs with long memories and is forced here with
+    STAR_XA_BWD=split in a child process (the switch is read once per process), then compared with this process."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from star_amd import ops
+out = {}
+for n, (B, h, L, K, hd, ilk) in enumerate([(6, 8, 100, 300, 128, False), (9, 4, 128, 150, 64, True)]):
+    g = torch.Generator().manual_seed(100 + n)
+    mk = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).cuda().requires_grad_()
+    q, k, v = mk(B, h, L, hd), mk(B, h, K, hd), mk(B, h, K, hd)
+    sc = torch.randn(B, K, generator=g).cuda().requires_grad_()
+    klen = torch.tensor([K] + [max(3, K - 29 * (i + 1)) for i in range(B - 1)], dtype=torch.int32).cuda()
+    o, _ = ops.xattn(q, k, v, bias=sc, key_len=klen, ilk_diag=2 if ilk else -1)
+    o.backward(torch.randn(o.shape, generator=g).to(torch.bfloat16).cuda())
+    for name, t in (("dq", q.grad), ("dk", k.grad), ("dv", v.grad), ("dsc", sc.grad)):
+        out[f"{name}{n}"] = t.float().cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("fused", "split"):
+        path = str(tmp_path / f"{mode}.npz")
+        env = dict(os.environ, STAR_XA_BWD=mode)
+        subprocess.run([sys.executable, "-c", script, root, path], check=True, env=env, timeout=110)
+        res[mode] = np.load(path)
+    for key in res["fused"].files:
+        a, b = res["fused"][key], res["split"][key]
+        assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max() + 1e-6, key
