@@ -307,10 +307,13 @@ def breakdown(scorer, inp, rate, dev):
     xs = inp.x.detach().clone().requires_grad_()
     s2 = scorer(xs).squeeze(-1)
     rows = (idx + torch.arange(B, device=dev).unsqueeze(1) * T).to(torch.int32).reshape(-1)
-    scorer.set_active_rows(rows)
     gsc = torch.zeros_like(s2)
     gsc.view(-1)[rows.long()] = 1.0
-    timed("scorer bwd (B*K rows, +dX)", lambda: torch.autograd.grad(s2, (xs, *scorer.parameters()), gsc, retain_graph=True))
+
+    def scorer_bwd():
+        scorer.set_active_rows(rows)              # single-use hint: set again for every backward
+        return torch.autograd.grad(s2, (xs, *scorer.parameters()), gsc, retain_graph=True)
+    timed("scorer bwd (B*K rows, +dX)", scorer_bwd)
     gm = torch.randn_like(mem)
     memg = ops.gather_rows(inp.s, idx)
     timed("gather rows bwd", lambda: torch.autograd.grad(memg, inp.s, gm, retain_graph=True))

@@ -5,10 +5,12 @@
  * mirror of those signatures lives in star_amd/nugget.py and binds these symbols through ctypes.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory,
- *     the library never allocates or frees device memory and keeps no mutable global state;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory
+ *     (workspaces, streams and events included): the library never allocates or frees device memory;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host
- *     synchronisation and no readback, and is re-entrant;
+ *     synchronisation and no readback, and is re-entrant and thread-safe: the only process-wide state is
+ *     a set of idempotent "kernel attribute set on device n" bits (atomics) and the test-only switches of
+ *     star_test_override();
  *   - return value: 0 on success, a negative STAR_ERR_* otherwise; star_last_error() then returns a
  *     thread-local message.  Nothing throws across the ABI;
  *   - tensors are dense row-major unless strides are given (strides are in ELEMENTS);
@@ -35,6 +37,16 @@ extern "C" {
 
 int star_version(void);
 const char* star_last_error(void);
+
+/* TEST-ONLY: force a kernel variant that the library would not pick on its own for the given shape, so that tests
+ * and A/B timing runs reach every kernel.  Process-wide atomics, 0 = the library's own choice (the default); not
+ * meant for product callers.  Returns the previous value (>= 0), or STAR_ERR_ARG for an unknown switch. */
+#define STAR_OVR_XA_BWD 0  /* attention backward: 1 = split dQ + dK/dV kernels, 2 = the fused kernel whenever legal */
+#define STAR_OVR_XA_DQ 1   /* 1 = the general (register-staged) dQ kernel */
+#define STAR_OVR_XA_DKV 2  /* 1 = the general dK/dV kernel */
+#define STAR_OVR_XA_NG 3   /* key groups of the attention forward / general dQ: 1 or 2 */
+#define STAR_OVR_COUNT 4
+int star_test_override(int which, int value);
 
 /* ---------------------------------------------------------------- a2 + a3: top-k anchor select
  * Replaces W2VASRModel.apply_nugget_compression (src/models/w2v_asr.py:208-244; copy at
@@ -67,8 +79,9 @@ int star_nugget_type_table(const int64_t* idx, const uint8_t* nugget_mask, int B
 /* ---------------------------------------------------------------- a4: row gather / scatter-add
  * Replaces semantic_repr[arange(B)[:,None], nugget_indices] (w2v_asr.py:566-567,
  * w2v_simul.py:446-447) and, with row_bytes == 4, the score gather of w2v_simul.py:427.
- * idx [B,K] int64; an index < 0 addresses frame T + idx (so -1 is the last frame), as in Python.
- * row_bytes must be a multiple of 4.  src [B,T,row], dst [B,K,row]. */
+ * idx [B,K] int64; an index < 0 addresses frame T + idx (so -1 is the last frame), as in Python.  An index
+ * outside [-T, T) (an IndexError in torch) is CLAMPED to the nearest frame, identically in forward and backward.
+ * row_bytes must be a multiple of 2.  src [B,T,row], dst [B,K,row]. */
 int star_gather_rows_fwd(const void* src, const int64_t* idx, void* dst, int B, int T, int K,
                          int64_t row_bytes, void* stream);
 /* Backward of the gather: dsrc[b,t,:] = sum_{j: idx[b,j]==t} ddst[b,j,:]  (index_put accumulate),
@@ -102,15 +115,23 @@ int star_cif_quantity_bwd(const float* alphas, const float* diff, const float* g
 /* ---------------------------------------------------------------- a6: CIF resize
  * Replaces W2VSimulModel.resize (w2v_simul.py:504-535, noise = 0): rescale each row to sum L_b,
  * then up to max_rounds (reference: 10) halve-and-add-mean fix-up rounds.  Row sums accumulate in
- * fp64 and are rounded once to fp32.  alphas [B,T] fp32 -> out [B,T] fp32 (may alias).  T <= 16384. */
+ * fp64 and are rounded once to fp32.  alphas [B,T] fp32 -> out [B,T] fp32 (may alias).  T <= 16384.
+ * fixups_out [B] int32 or NULL: the number of fix-ups applied to each row (what the backward needs). */
 int star_cif_resize(const float* alphas, const int32_t* target_lengths, float threshold,
-                    int max_rounds, int B, int T, float* out, void* stream);
+                    int max_rounds, int B, int T, float* out, int32_t* fixups_out, void* stream);
+/* Backward of resize: the gradient that lm_cif_training sends through it into the scorer (w2v_simul.py:558,
+ * w2v_asr.py:679; the nugget path detaches its output, w2v_simul.py:426).  alphas = the forward's INPUT,
+ * fixups = the forward's fixups_out (NULL = no fix-ups), dout [B,T] fp32 -> dalphas [B,T] fp32.  The mask
+ * (row != 0) and its count are constants, as in the reference's autograd graph (w2v_simul.py:529-532). */
+int star_cif_resize_bwd(const float* alphas, const int32_t* target_lengths, const int32_t* fixups,
+                        const float* dout, int B, int T, float* dalphas, void* stream);
 
 /* ---------------------------------------------------------------- a7: cumulative fire scan
  * Replaces apply_threshold_yield_nugget + get_valid_mask_indices (w2v_simul.py:376-403,196-220).
  * Exact serial fp32 recurrence per utterance over all T frames:
  *   cur = fl(cur + a_t*mask_t); fire = cur >= 1 || t == n_b-1; cur = fl(cur-1) if fire.
- *   alphas [B,T] fp32; attn_mask [B,T] uint8 or NULL (then lengths [B] int32 defines a prefix mask)
+ *   alphas [B,T] fp32; attn_mask [B,T] uint8 or NULL (then lengths [B] int32 defines a prefix mask; a
+ *          length > T makes every frame valid and switches the forced last-frame fire off for that row)
  *   cap    width of the index outputs (>= max fire count; fires beyond cap are dropped and
  *          counted in counts, so the caller can detect overflow)
  *   scores optional [B,T] fp32: scores_gather[b,j] = scores[b, idx] (idx -1 -> frame T-1)
@@ -183,14 +204,17 @@ int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float*
  * aux_stream (may be NULL): a second stream of the same device.  When given, the memory-bound helpers of the
  *   call (dx zero-fill, X_sel^T, the split-K / column reductions) run on it beside the GEMMs; the call forks from
  *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
- *   `stream` captures both branches).  Calls with different stream pairs must not overlap on one device.
+ *   `stream` captures both branches).
+ * aux_events_host: HOST array of four hipEvent_t created by the caller (hipEventDisableTiming suffices), required
+ *   when aux_stream is given: the fork / join events of this call.  One set per (stream, aux_stream) pair: calls that
+ *   may overlap in time (other threads, other stream pairs) bring their own sets, so the library holds no event.
  * workspace: star_scorer_bwd_workspace(R,d) bytes. */
 size_t star_scorer_bwd_workspace(int64_t R, int d);
 int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1,
                     const float* w2, const float* dscores, const int32_t* rows, int64_t R,
                     int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
                     int dx_zeroed, void* workspace, size_t workspace_bytes, void* stream,
-                    void* aux_stream);
+                    void* aux_stream, void* const* aux_events_host);
 /* fp32 [rows,cols] -> bf16 copy and bf16 transpose (the per-step weight cast of W1). */
 int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream);
 
@@ -205,7 +229,24 @@ int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, vo
  *        (the reference uses 2, my_transformer.py:566)
  *   lse [B,h,L] fp32: log-sum-exp of the masked, biased logits (saved for backward)
  *   p_out optional [B,h,L,Kn] fp32 attention weights (output_attentions), NULL to skip
- * hd in {64, 96, 128}. */
+ * hd in {64, 96, 128}.
+ *
+ * Attention-probability dropout (self.attn_dropout, my_transformer.py:595; GPT2Config.attn_pdrop, 0.1 in the
+ * reference's default decoder config, w2v_asr.py:134-145):  dropout_p in [0, 1).  With dropout_p > 0
+ *   O = (P o M) V / (1 - p_eff),  M[b,h,i,j] = keep(b,h,i,j) in {0,1},
+ * LSE is that of the undropped softmax, p_out (if requested) holds the dropped, rescaled weights (what the
+ * reference returns as attn_weights), and star_xattn_bwd regenerates the same mask from the same (seed, offset).
+ * The mask is a pure function of (seed, offset, b, h, i, j) -- a counter-based generator, specified here so that
+ * a caller (or a test) can reproduce it:
+ *   mix(x)   = x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16      (uint32)
+ *   k1       = mix(lo32(seed) ^ mix(hi32(seed) ^ mix(lo32(offset) ^ mix(hi32(offset) + 0x9e3779b9 * (b*h_count + h + 1)))))
+ *   k2       = mix(k1 ^ 0x85ebca6b)
+ *   x        = k1 + i * Kn + j;  x ^= x >> 16; x *= 0x7feb352d; x ^= k2; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16
+ *   keep     = x >= thr,  thr = min(floor(dropout_p * 2^32), 2^32 - 1),  p_eff = thr / 2^32
+ * rng_state (optional DEVICE pointer to two uint64 {seed, offset}): when non-NULL the kernels read seed / offset
+ * from it at run time instead of the two fields, so a step captured in a HIP graph can draw a fresh mask at every
+ * replay (the caller advances the offset with its own stream-ordered write between forward calls).
+ * dropout_p == 0 runs exactly the kernels (and produces exactly the bits) of a build without dropout. */
 typedef struct {
     int B, h, L, Kn, hd;
     int64_t q_sb, q_sh, q_sr;
@@ -215,6 +256,10 @@ typedef struct {
     int bias_len;
     int ilk_diag;
     float scale;
+    float dropout_p;
+    uint64_t seed;
+    uint64_t offset;
+    const uint64_t* rng_state;
 } star_xattn_shape;
 
 int star_xattn_fwd(const void* q, const void* k, const void* v, const float* bias,

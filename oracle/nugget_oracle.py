@@ -19,7 +19,8 @@ Reference lines restated (all paths relative to the reference checkout):
   quantity_loss               src/models/w2v_simul.py:419-424
   resize                      src/models/w2v_simul.py:504-535
   fire_scan / block mask      src/models/w2v_simul.py:196-220,376-403
-  xattn_core                  src/models/my_transformer.py:535-603
+  xattn_core                  src/models/my_transformer.py:535-603 (attention dropout :595 with a given mask)
+  valid_mask_indices          src/models/w2v_simul.py:196-220
   cif_aggregate               src/models/w2v_simul.py:558-606, w2v_asr.py:681-722  
 """
 from __future__ import annotations
@@ -131,7 +132,7 @@ def quantity_loss(scores: torch.Tensor, attn_mask: torch.Tensor,
 
 # --------------------------------------------------------------------------- a6
 def resize(alphas: torch.Tensor, target_lengths: torch.Tensor, threshold: float = 1.0,
-           max_rounds: int = 10) -> torch.Tensor:
+           max_rounds: int = 10, differentiable: bool = False) -> torch.Tensor:
     """CIF weight rescale + halve-and-add-mean fix-ups (w2v_simul.py:504-535, noise = 0).
 
     Rows are independent, so the reference's batch-global loop is restated per row:
@@ -140,25 +141,45 @@ def resize(alphas: torch.Tensor, target_lengths: torch.Tensor, threshold: float 
     by 0.5*row + (0.5*sum(row)/nnz(row))*(row != 0).  A row with no offender in a round is
     finished (nothing else can change it).  Sums use torch's fp32 CPU reduction so that
     the restatement matches the reference bit-for-bit on the golden vectors.
+
+    differentiable=True keeps the autograd graph, as the reference's own resize does (lm_cif_training
+    back-propagates the LM loss through it, w2v_simul.py:558): the fix-up decisions and the mask row.ne(0) are
+    constants of the graph, the scale and the row sums are not.
     """
-    a = alphas.detach().to(torch.float32).clone()
+    a = alphas.to(torch.float32) if differentiable else alphas.detach().to(torch.float32).clone()
     num = target_lengths.to(torch.float32)
     den = a.sum(-1)
     a = a * (num / den)[:, None]
     thr = float(threshold)
+    rows = []
     for b in range(a.shape[0]):
         row = a[b]
         for _ in range(max_rounds):
-            offenders = torch.nonzero(row > thr).flatten().tolist()
+            offenders = torch.nonzero(row.detach() > thr).flatten().tolist()
             if not offenders:
                 break
             for y in offenders:
-                if float(row[y]) >= thr:
-                    nz = row.ne(0).to(torch.float32)
+                if float(row.detach()[y]) >= thr:
+                    nz = row.detach().ne(0).to(torch.float32)
                     mean = 0.5 * row.sum() / nz.sum()
                     row = row * 0.5 + mean * nz
-        a[b] = row
-    return a
+        rows.append(row)
+    return torch.stack(rows, 0)
+
+
+def valid_mask_indices(mask: np.ndarray, padding_value: int = -1):
+    """get_valid_mask_indices (w2v_simul.py:196-220): ascending positions of the True entries of each row, padded
+    with padding_value to the largest count.  Returns (indices [B,Kmax] (or [Kmax] for a 1-D mask), Kmax, counts)."""
+    m = np.asarray(mask).astype(bool)
+    one_d = m.ndim == 1
+    m2 = m[None, :] if one_d else m
+    counts = m2.sum(axis=1).astype(np.int64)
+    kmax = int(counts.max())
+    idx = np.full((m2.shape[0], kmax), padding_value, dtype=np.int64)
+    for b in range(m2.shape[0]):
+        pos = np.flatnonzero(m2[b])
+        idx[b, :pos.size] = pos
+    return (idx[0], kmax, counts[0]) if one_d else (idx, kmax, counts)
 
 
 # --------------------------------------------------------------------------- a7
@@ -215,14 +236,56 @@ def block_mask_from_fires(nugget_indices: np.ndarray, attn_mask: np.ndarray) -> 
 
 
 # --------------------------------------------------------------------------- a8
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_keep_mask(seed: int, offset: int, bsz: int, heads: int, lq: int, lk: int, p: float):
+    """The counter-based keep mask of the attention kernels, restated from its specification in
+    include/star_nugget.h (star_xattn_shape).  NOT a reference algorithm: the reference draws its mask from
+    torch's generator (nn.Dropout, my_transformer.py:595), which no other implementation can reproduce; what IS
+    pinned against the reference is where the mask enters (xattn_core(drop_mask=...), golden xattn_drop*).
+    Returns (keep [B,h,L,K] bool, p_eff)."""
+    with np.errstate(over="ignore"):
+        t = float(np.float32(p)) * 4294967296.0
+        thr = np.uint32(0xFFFFFFFF) if t >= 4294967295.0 else np.uint32(int(t))
+        p_eff = float(thr) / 4294967296.0
+        seed, offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+        bh = np.arange(bsz * heads, dtype=np.uint32)
+        stream = (np.uint32(0x9E3779B9) * (bh + np.uint32(1))).astype(np.uint32)
+        k1 = _mix32((np.uint32(offset >> 32) + stream).astype(np.uint32))
+        k1 = _mix32(np.uint32(offset & 0xFFFFFFFF) ^ k1)
+        k1 = _mix32(np.uint32(seed >> 32) ^ k1)
+        k1 = _mix32(np.uint32(seed & 0xFFFFFFFF) ^ k1)
+        k2 = _mix32(k1 ^ np.uint32(0x85EBCA6B))
+        ctr = (np.arange(lq, dtype=np.uint32)[:, None] * np.uint32(lk) + np.arange(lk, dtype=np.uint32)[None, :])
+        x = (k1[:, None, None] + ctr[None]).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+        x ^= k2[:, None, None]
+        x ^= x >> np.uint32(15)
+        x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+    return (x >= thr).reshape(bsz, heads, lq, lk), p_eff
+
+
 def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                key_mask: torch.Tensor | None, scorer_logits: torch.Tensor | None,
-               limit_cross_attn: bool = False, scale: bool = True):
-    """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch,
-    dropout p = 0, head_mask None).
+               limit_cross_attn: bool = False, scale: bool = True,
+               drop_mask: torch.Tensor | None = None, drop_p: float = 0.0):
+    """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch, head_mask None).
 
     q [B,h,L,hd], k/v [B,h,K,hd], key_mask [B,K] bool (True = attend), scorer_logits [B,Kb]
-    with Kb <= K (zero-extended, my_transformer.py:114-125 variant).  Returns (O, P).
+    with Kb <= K (zero-extended, my_transformer.py:114-125 variant).  drop_mask [B,h,L,K] (1 = keep) with
+    drop_p: the attention-probability dropout of my_transformer.py:595 with the mask GIVEN, P <- P*mask/(1-p)
+    after the softmax (and after the cast to V's dtype), before P.V.  Returns (O, P) with P the dropped weights,
+    as the reference returns them.
     """
     a = q @ k.transpose(-1, -2)
     if scale:
@@ -244,6 +307,8 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
             s = torch.cat([s, s.new_zeros(s.shape[0], lk - s.shape[1])], dim=1)
         a = a + s[:, None, None, :].to(a.dtype)
     p = torch.softmax(a, dim=-1)
+    if drop_mask is not None:
+        p = p * drop_mask.to(p.dtype) / (1.0 - drop_p)
     return p @ v, p
 
 

@@ -24,7 +24,8 @@ class XAttnShape(C.Structure):
                 ("k_sb", C.c_int64), ("k_sh", C.c_int64), ("k_sr", C.c_int64),
                 ("v_sb", C.c_int64), ("v_sh", C.c_int64), ("v_sr", C.c_int64),
                 ("o_sb", C.c_int64), ("o_sh", C.c_int64), ("o_sr", C.c_int64),
-                ("bias_len", C.c_int), ("ilk_diag", C.c_int), ("scale", C.c_float)]
+                ("bias_len", C.c_int), ("ilk_diag", C.c_int), ("scale", C.c_float),
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64), ("rng_state", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -37,6 +38,7 @@ _SZ = C.c_size_t
 SIGNATURES = {
     "star_version": (_I, []),
     "star_last_error": (C.c_char_p, []),
+    "star_test_override": (_I, [_I, _I]),
     "star_topk_select": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "star_nugget_type_table": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "star_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I64, _P]),
@@ -49,7 +51,8 @@ SIGNATURES = {
     "star_diag_fanout_bwd": (_I, [C.POINTER(C.c_void_p), _I, _P, _I64, _I, _P, _P]),
     "star_cif_quantity_fwd": (_I, [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
     "star_cif_quantity_bwd": (_I, [_P, _P, _P, _F, _I, _I, _I, _P, _P]),
-    "star_cif_resize": (_I, [_P, _P, _F, _I, _I, _I, _P, _P]),
+    "star_cif_resize": (_I, [_P, _P, _F, _I, _I, _I, _P, _P, _P]),
+    "star_cif_resize_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -58,7 +61,8 @@ SIGNATURES = {
     "star_scorer_fwd_workspace": (_SZ, [_I64, _I]),
     "star_scorer_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _SZ, _P]),
     "star_scorer_bwd_workspace": (_SZ, [_I64, _I]),
-    "star_scorer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P, _P]),
+    "star_scorer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P, _P,
+                             C.POINTER(C.c_void_p)]),
     "star_cast_transpose_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
     "star_xattn_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P]),
     "star_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P, _P, _P, _I, _P]),

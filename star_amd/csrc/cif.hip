@@ -73,7 +73,8 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_quantity_bwd_kernel(const flo
 __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __restrict__ alphas,
                                                                  const int32_t* __restrict__ target_lengths,
                                                                  float threshold, int max_rounds, int T,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out,
+                                                                 int32_t* __restrict__ fixups_out) {
     extern __shared__ float rs_smem[];
     float* row = rs_smem;                          // [T]
     uint32_t* snap = (uint32_t*)(row + T);         // [(T+31)/32] offender snapshot bits
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
     float scale = __fdiv_rn((float)target_lengths[b], den);
     for (int i = tid; i < T; i += CIF_THREADS) row[i] = __fmul_rn(row[i], scale);
     __syncthreads();
+    int nfix = 0;                                  // fix-ups applied to this row (uniform): the backward needs it
     for (int round = 0; round < max_rounds; ++round) {
         // snapshot of the offenders (value > thr), as torch.where does at the top of a round
         if (tid == 0) flag = 0;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
                 int y = w * 32 + __builtin_ctz(bits);
                 bits &= bits - 1;
                 if (row[y] >= threshold) {  // uniform: re-check the CURRENT value
+                    ++nfix;
                     double s = 0.0, nz = 0.0;
                     for (int i = tid; i < T; i += CIF_THREADS) {
                         float a = row[i];
@@ -132,6 +135,49 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
         __syncthreads();
     }
     for (int i = tid; i < T; i += CIF_THREADS) out[(size_t)b * T + i] = row[i];
+    if (fixups_out && tid == 0) fixups_out[b] = nfix;
+}
+
+// Backward of resize (the gradient lm_cif_training sends through it, w2v_simul.py:558 / w2v_asr.py:679).
+// Forward per row: r0 = a * c, c = L / S, S = sum(a); then k fix-ups r <- 0.5 r + (0.5 sum(r) / n) m with
+// m = (r != 0), n = |m| (constants of the graph, w2v_simul.py:529-532).  m does not change between fix-ups (zeros
+// stay zero; non-zero entries of a sigmoid output stay positive), and s = <m, g> is invariant under the transposed
+// fix-up g <- 0.5 g + (0.5 <m, g> / n) 1, so k of them collapse to  g_k = 2^-k g + (s / n)(1 - 2^-k) 1.
+// Then d a_i = c (g_k,i - <g_k, a> / S).  Sums in fp64 (fixed order), one workgroup per row.
+__global__ __launch_bounds__(CIF_THREADS) void cif_resize_bwd_kernel(const float* __restrict__ alphas,
+                                                                     const int32_t* __restrict__ target_lengths,
+                                                                     const int32_t* __restrict__ fixups,
+                                                                     const float* __restrict__ dout, int T,
+                                                                     float* __restrict__ dalphas) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* a = alphas + (size_t)b * T;
+    const float* g = dout + (size_t)b * T;
+    double S = 0.0, sg = 0.0, nz = 0.0, ga = 0.0, asum = 0.0;
+    for (int i = tid; i < T; i += CIF_THREADS) {
+        const double ai = a[i], gi = g[i];
+        S += ai;
+        if (a[i] != 0.0f) {
+            sg += gi;
+            nz += 1.0;
+        }
+        ga += gi * ai;
+    }
+    S = block_sum_f64(S, red);
+    sg = block_sum_f64(sg, red);
+    nz = block_sum_f64(nz, red);
+    ga = block_sum_f64(ga, red);
+    asum = S;
+    const int k = fixups ? fixups[b] : 0;
+    const double w = k > 0 ? ldexp(1.0, -min(k, 1000)) : 1.0;            // 2^-k
+    const double add = (k > 0 && nz > 0.0) ? (sg / nz) * (1.0 - w) : 0.0;
+    // <g_k, a> = w <g, a> + add * sum(a)
+    const double dot = w * ga + add * asum;
+    const double c = (double)target_lengths[b] / S;
+    for (int i = tid; i < T; i += CIF_THREADS) {
+        const double gk = w * (double)g[i] + add;
+        dalphas[(size_t)b * T + i] = (float)(c * (gk - dot / S));
+    }
 }
 
 // ------------------------------------------------------------------------------------------ a7
@@ -187,7 +233,9 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
             c = wave_sum(c);
             if ((tid & 63) == 0) atomicAdd(&lens[r], c);
         } else if (tid == 0) {
-            lens[r] = n_r;
+            // unclamped: a length > T means "every frame valid and NO forced last-frame fire" (the threshold row
+            // below then has no -inf inside [0, T); get_valid_mask_indices relies on it)
+            lens[r] = lengths[b0 + r];
         }
     }
     __syncthreads();
@@ -286,7 +334,7 @@ extern "C" int star_cif_quantity_bwd(const float* alphas, const float* diff, con
 }
 
 extern "C" int star_cif_resize(const float* alphas, const int32_t* target_lengths, float threshold, int max_rounds,
-                               int B, int T, float* out, void* stream) {
+                               int B, int T, float* out, int32_t* fixups_out, void* stream) {
     using namespace star;
     STAR_REQUIRE(alphas && target_lengths && out, "star_cif_resize: null pointer");
     STAR_REQUIRE(B >= 1 && T >= 1 && T <= 16384, "star_cif_resize: bad shape B=%d T=%d (T <= 16384)", B, T);
@@ -300,8 +348,19 @@ extern "C" int star_cif_resize(const float* alphas, const int32_t* target_length
         }
     }
     hipLaunchKernelGGL(cif_resize_kernel, dim3(B), dim3(CIF_THREADS), smem, (hipStream_t)stream, alphas,
-                       target_lengths, threshold, max_rounds, T, out);
+                       target_lengths, threshold, max_rounds, T, out, fixups_out);
     STAR_LAUNCH_CHECK("star_cif_resize");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_resize_bwd(const float* alphas, const int32_t* target_lengths, const int32_t* fixups,
+                                   const float* dout, int B, int T, float* dalphas, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alphas && target_lengths && dout && dalphas, "star_cif_resize_bwd: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1, "star_cif_resize_bwd: bad shape B=%d T=%d", B, T);
+    hipLaunchKernelGGL(cif_resize_bwd_kernel, dim3(B), dim3(CIF_THREADS), 0, (hipStream_t)stream, alphas,
+                       target_lengths, fixups, dout, T, dalphas);
+    STAR_LAUNCH_CHECK("star_cif_resize_bwd");
     return STAR_OK;
 }
 
@@ -317,17 +376,10 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
     const int R = scan_rows_per_wg(B, T);
     const size_t smem = (size_t)R * scan_pitch(T) * 8;
     if (smem > 48 * 1024) {
-        static bool done[64] = {};
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (!done[dev & 63]) {
-            hipError_t e = hipFuncSetAttribute((const void*)cif_fire_scan_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-            if (e != hipSuccess) {
-                set_error("star_cif_fire_scan: cannot reserve LDS: %s", hipGetErrorString(e));
-                return STAR_ERR_LAUNCH;
-            }
-            done[dev & 63] = true;
+        static DevOnce once;
+        if (!reserve_lds_once(once, (const void*)cif_fire_scan_kernel, 152 * 1024)) {
+            set_error("star_cif_fire_scan: cannot reserve LDS");
+            return STAR_ERR_LAUNCH;
         }
     }
     if (max_count) {

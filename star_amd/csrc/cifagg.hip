@@ -251,16 +251,10 @@ extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int
     const size_t smem = (size_t)R * cw_row_bytes(T);
     STAR_REQUIRE(T < 32768, "star_cif_weights: T too large");
     if (smem > 48 * 1024) {
-        static bool attr_done[64] = {};
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (!attr_done[dev & 63]) {
-            if (hipFuncSetAttribute((const void*)cif_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    140 * 1024) != hipSuccess) {
-                set_error("star_cif_weights: cannot reserve LDS");
-                return STAR_ERR_LAUNCH;
-            }
-            attr_done[dev & 63] = true;
+        static DevOnce once;
+        if (!reserve_lds_once(once, (const void*)cif_weights_kernel, 140 * 1024)) {
+            set_error("star_cif_weights: cannot reserve LDS");
+            return STAR_ERR_LAUNCH;
         }
     }
     hipLaunchKernelGGL(cif_weights_kernel, dim3(cdiv(B, R)), dim3(256), smem, (hipStream_t)stream, alphas, threshold, B,

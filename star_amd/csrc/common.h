@@ -4,11 +4,30 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/star_nugget.h"
 
 namespace star {
 
 void set_error(const char* fmt, ...);
+// test-only kernel-variant switches (star_test_override in star_nugget.h); 0 = the library's own choice
+int test_override(int which);
+
+// "done once per device" flag for idempotent set-up calls (hipFuncSetAttribute costs tens of microseconds on the
+// host): a bit per device, set with release order after the call succeeded.  Two threads that race on the first
+// use both make the (idempotent, thread-safe) HIP call; nothing else is shared.
+struct DevOnce {
+    std::atomic<uint64_t> bits{0};
+};
+static inline bool reserve_lds_once(DevOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (once.bits.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    once.bits.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 #define STAR_REQUIRE(cond, ...)                         \
     do {                                                \

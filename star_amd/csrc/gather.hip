@@ -14,6 +14,16 @@
 
 namespace star {
 
+// Index normalisation shared by the forward and every backward path: Python-style wrap of negative indices, then a
+// CLAMP into [0, T) (torch would raise IndexError for an index outside [-T, T); a kernel cannot, so both directions
+// agree on the same frame instead: the gradient of a clamped slot lands on the frame the forward read).
+__device__ __forceinline__ int64_t gather_frame(int64_t t, int T) {
+    if (t < 0) t += T;
+    if (t < 0) t = 0;
+    if (t >= T) t = T - 1;
+    return t;
+}
+
 template <typename V>
 __global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const V* __restrict__ src,
                                                               const int64_t* __restrict__ idx,
@@ -23,10 +33,7 @@ __global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const V* __restric
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_total) return;
     int64_t b = row / K;
-    int64_t t = idx[row];
-    if (t < 0) t += T;
-    if (t < 0) t = 0;
-    if (t >= T) t = T - 1;
+    const int64_t t = gather_frame(idx[row], T);
     const V* s = src + ((size_t)b * T + t) * vec_per_row;
     V* d = dst + (size_t)row * vec_per_row;
     for (int c = lane; c < vec_per_row; c += 64) d[c] = s[c];
@@ -59,10 +66,9 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
     __syncthreads();
     const int64_t* irow = idx + (size_t)b * K;
     for (int j = tid; j < K; j += 256) {
-        int64_t t = irow[j];
-        if (t < 0) t += T;
+        const int64_t t = gather_frame(irow[j], T);
         int r = (int)(t - t0);
-        if (t >= 0 && t < T && r >= 0 && r < GB_TILE) {
+        if (r >= 0 && r < GB_TILE) {
             atomicAdd(&count[r], 1);
             atomicMin(&first_j[r], j);
         }
@@ -96,9 +102,7 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
                 const int j = j0 + lane;
                 bool m = false;
                 if (j < K && j >= jf) {
-                    int64_t tj = irow[j];
-                    if (tj < 0) tj += T;
-                    m = (tj == t);
+                    m = (gather_frame(irow[j], T) == t);
                 }
                 unsigned long long bal = __ballot(m);
                 // four matching rows per round: all their loads are issued before the first add (one wave owns the
@@ -150,9 +154,7 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
                 for (int j = first_j[r]; j < K; ++j) {
-                    int64_t tj = irow[j];
-                    if (tj < 0) tj += T;
-                    if (tj != t) continue;
+                    if (gather_frame(irow[j], T) != t) continue;
                     vec4 x = ((const vec4*)(ddst + ((size_t)b * K + j) * d))[v];
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) acc[q] += (float)x.v[q];
@@ -246,12 +248,16 @@ extern "C" int star_gather_rows_fwd(const void* src, const int64_t* idx, void* d
                                     int64_t row_bytes, void* stream) {
     using namespace star;
     STAR_REQUIRE(src && idx && dst, "star_gather_rows_fwd: null pointer");
-    STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && row_bytes >= 4 && row_bytes % 4 == 0,
+    STAR_REQUIRE(B >= 1 && T >= 1 && K >= 1 && row_bytes >= 2 && row_bytes % 2 == 0,
                  "star_gather_rows_fwd: bad shape B=%d T=%d K=%d row_bytes=%lld", B, T, K, (long long)row_bytes);
     int64_t rows = (int64_t)B * K;
     dim3 grid(cdiv(rows, 4)), block(256);
     bool a16 = (row_bytes % 16 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
-    if (a16)
+    if (row_bytes % 4 != 0 || (((uintptr_t)src | (uintptr_t)dst) % 4 != 0))
+        // 2-byte granules: the bf16 score gather (d = 1, w2v_simul.py:427 under bf16) and odd bf16 row lengths
+        hipLaunchKernelGGL(gather_rows_fwd_kernel<uint16_t>, grid, block, 0, (hipStream_t)stream,
+                           (const uint16_t*)src, idx, (uint16_t*)dst, T, K, rows, (int)(row_bytes / 2));
+    else if (a16)
         hipLaunchKernelGGL(gather_rows_fwd_kernel<u32x4>, grid, block, 0, (hipStream_t)stream, (const u32x4*)src,
                            idx, (u32x4*)dst, T, K, rows, (int)(row_bytes / 16));
     else
@@ -283,9 +289,7 @@ __global__ __launch_bounds__(256) void scatter_scalar_bwd_kernel(const T_ELEM* _
         acc[t] = 0.f;
     }
     for (int j = tid; j < K; j += 256) {
-        int64_t t = idx[(size_t)b * K + j];
-        if (t < 0) t += T;
-        tj[j] = (t >= 0 && t < T) ? (int)t : -1;
+        tj[j] = (int)star::gather_frame(idx[(size_t)b * K + j], T);
         gj[j] = (float)ddst[(size_t)b * K + j];
     }
     __syncthreads();
@@ -323,19 +327,13 @@ extern "C" int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* 
     if (d == 1 && T <= GS_MAX && K <= GS_MAX) {
         const size_t smem = ((size_t)3 * T + (size_t)2 * K) * 4;
         if (smem > 48 * 1024) {
-            static bool done[2][64] = {};
-            int dev = 0;
-            hipGetDevice(&dev);
+            static DevOnce once[2];
             const int w = dtype == STAR_DT_BF16 ? 0 : 1;
-            if (!done[w][dev & 63]) {
-                const void* fn = w == 0 ? (const void*)scatter_scalar_bwd_kernel<__bf16>
-                                        : (const void*)scatter_scalar_bwd_kernel<float>;
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * GS_MAX + 2 * GS_MAX) * 4) !=
-                    hipSuccess) {
-                    set_error("star_gather_rows_bwd: cannot reserve LDS");
-                    return STAR_ERR_LAUNCH;
-                }
-                done[w][dev & 63] = true;
+            const void* fn = w == 0 ? (const void*)scatter_scalar_bwd_kernel<__bf16>
+                                    : (const void*)scatter_scalar_bwd_kernel<float>;
+            if (!reserve_lds_once(once[w], fn, (3 * GS_MAX + 2 * GS_MAX) * 4)) {
+                set_error("star_gather_rows_bwd: cannot reserve LDS");
+                return STAR_ERR_LAUNCH;
             }
         }
         if (dtype == STAR_DT_BF16)

@@ -26,7 +26,6 @@
 // A panel is fetched into one L2 instead of eight.
 // Algorithmic work: forward 2*N_f*d*(d+1) FLOP; bytes: X 2*d*N_f + W1 2*d*d read, scores 4*N_f written.
 #include "common.h"
-#include <stdlib.h>
 
 namespace star {
 
@@ -679,32 +678,42 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
-    static bool attr_done[64] = {};
-    static int cus[64] = {};
+    static DevOnce once[4];
+    static std::atomic<int> cus[64];
     int dev = 0;
-    hipGetDevice(&dev);
-    dev &= 63;
-    if (!attr_done[dev]) {
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, SCORE_LDS);
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_DH>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_LDS);
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        cus[dev] = n / 8 * 8;
-        attr_done[dev] = true;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_error("scorer GEMM: hipGetDevice failed");
+        return STAR_ERR_LAUNCH;
+    }
+    bool ok = true;
+    switch (epi) {
+        case EPI_SCORE: ok = reserve_lds_once(once[0], (const void*)gemm_nt_kernel<EPI_SCORE>, SCORE_LDS); break;
+        case EPI_DH: ok = reserve_lds_once(once[1], (const void*)gemm_nt_kernel<EPI_DH>, EPI_LDS); break;
+        case EPI_SLAB: ok = reserve_lds_once(once[2], (const void*)gemm_nt_kernel<EPI_SLAB>, GEMM_LDS); break;
+        default: ok = reserve_lds_once(once[3], (const void*)gemm_nt_kernel<EPI_ROWS>, EPI_LDS); break;
+    }
+    if (!ok) {
+        set_error("scorer GEMM: cannot reserve the kernel's LDS (hipFuncSetAttribute failed)");
+        return STAR_ERR_LAUNCH;
     }
     switch (epi) {
-        case EPI_SCORE:
+        case EPI_SCORE: {
             // persistent: one workgroup per CU (a multiple of 8 keeps every workgroup on its XCD) walks the tiles
-            if (grid > cus[dev]) grid = cus[dev];
+            int n = cus[dev & 63].load(std::memory_order_relaxed);
+            if (n == 0) {
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+                n = n / 8 * 8;
+                cus[dev & 63].store(n, std::memory_order_relaxed);
+            }
+            if (grid > n) grid = n;
             hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
             break;
+        }
         case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
         default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
     }
-    return 0;
+    return STAR_OK;
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -748,38 +757,12 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
     p.partial = (float*)workspace;
     p.partial_ld = round_up(N, BM);
     hipStream_t st = (hipStream_t)stream;
-    launch_gemm(EPI_SCORE, p, st);
+    if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;
     hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
                        p.partial_ld, (d + BN - 1) / BN, b2, N, scores);
     STAR_LAUNCH_CHECK("star_scorer_fwd");
     return STAR_OK;
 }
-
-namespace star {
-// Fork / join between the caller's stream and its auxiliary stream (both supplied by the caller).  The events are
-// created once per device and reused: an event only orders work recorded before the wait, so back-to-back calls
-// on the same pair of streams are safe; calls on different stream pairs must not run concurrently on one device.
-struct AuxEvents {
-    hipEvent_t fork[2], join[2];
-    bool ok;
-};
-static AuxEvents* aux_events() {
-    static AuxEvents ev[64] = {};
-    int dev = 0;
-    hipGetDevice(&dev);
-    AuxEvents* e = &ev[dev & 63];
-    if (!e->ok) {
-        bool good = true;
-        for (int i = 0; i < 2; ++i) {
-            good = good && hipEventCreateWithFlags(&e->fork[i], hipEventDisableTiming) == hipSuccess;
-            good = good && hipEventCreateWithFlags(&e->join[i], hipEventDisableTiming) == hipSuccess;
-        }
-        e->ok = good;
-        if (!good) return nullptr;
-    }
-    return e;
-}
-}  // namespace star
 
 extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
     using namespace star;
@@ -793,7 +776,8 @@ extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
 extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1, const float* w2,
                                const float* dscores, const int32_t* rows, int64_t R, int64_t N, int d, float* dw1,
                                float* db1, float* dw2, float* db2, void* dx, int dx_zeroed, void* workspace,
-                               size_t workspace_bytes, void* stream, void* aux_stream) {
+                               size_t workspace_bytes, void* stream, void* aux_stream,
+                               void* const* aux_events_host) {
     using namespace star;
     STAR_REQUIRE(x && w1 && b1 && w2 && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
                  "star_scorer_bwd: null pointer");
@@ -819,17 +803,34 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     // Two independent chains: the MFMA-bound GEMMs stay on `stream`; the memory-bound helpers (zero-fill of dx,
     // X_sel^T, the slab / column reductions) run beside them on `aux_stream` when the caller provides one.
     hipStream_t aux = aux_stream ? (hipStream_t)aux_stream : st;
-    AuxEvents* ev = (aux != st) ? aux_events() : nullptr;
-    if (aux != st && !ev) aux = st;                    // could not create events: run serially
+    // fork / join events belong to the caller (one set per stream pair): the library keeps no event of its own
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
     if (aux != st) {
-        hipEventRecord(ev->fork[0], st);
-        hipStreamWaitEvent(aux, ev->fork[0], 0);
+        STAR_REQUIRE(aux_events_host && aux_events_host[0] && aux_events_host[1] && aux_events_host[2] &&
+                         aux_events_host[3],
+                     "star_scorer_bwd: aux_stream given without its four events");
+        ev_fork[0] = (hipEvent_t)aux_events_host[0];
+        ev_join[0] = (hipEvent_t)aux_events_host[1];
+        ev_fork[1] = (hipEvent_t)aux_events_host[2];
+        ev_join[1] = (hipEvent_t)aux_events_host[3];
+    }
+#define STAR_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            set_error("star_scorer_bwd: %s failed: %s", #call, hipGetErrorString(e_));              \
+            return STAR_ERR_LAUNCH;                                                                 \
+        }                                                                                           \
+    } while (0)
+    if (aux != st) {
+        STAR_HIP(hipEventRecord(ev_fork[0], st));
+        STAR_HIP(hipStreamWaitEvent(aux, ev_fork[0], 0));
     }
     // aux: dx zero-fill (rows that are not listed) and X_sel^T
-    if (dx && !dx_zeroed) hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux);
+    if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
     hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
                        (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
-    if (aux != st) hipEventRecord(ev->join[0], aux);
+    if (aux != st) STAR_HIP(hipEventRecord(ev_join[0], aux));
     // 1. recompute H for the listed rows, emit G = dH and G^T, column partials for dw2 / db1
     GemmParams p = {};
     p.A = (const __bf16*)x;
@@ -849,8 +850,8 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     p.GT = GT;
     p.ldgt = Rpad;
     p.colpart = colpart;
-    launch_gemm(EPI_DH, p, st);
-    if (aux != st) hipStreamWaitEvent(st, ev->join[0], 0);
+    if (int rc = launch_gemm(EPI_DH, p, st)) return rc;
+    if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));
     // 2. dW1 = G^T . X_sel  (split-K slabs)
     GemmParams q = {};
     q.A = GT;
@@ -862,17 +863,17 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     q.kchunks = (int)(Rpad / BK);
     q.splits = splits;
     q.slab = slab;
-    launch_gemm(EPI_SLAB, q, st);
+    if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
     // 3. reductions (on aux, beside the dX GEMM)
     if (aux != st) {
-        hipEventRecord(ev->fork[1], st);
-        hipStreamWaitEvent(aux, ev->fork[1], 0);
+        STAR_HIP(hipEventRecord(ev_fork[1], st));
+        STAR_HIP(hipStreamWaitEvent(aux, ev_fork[1], 0));
     }
     const int64_t dd = (int64_t)d * d;
     const int nblk_dw1 = cdiv(dd, 1024);
     hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(nblk_dw1 + 2 * d / 64), dim3(256), 0, aux, (const float*)slab,
                        splits, dd, dw1, (const float*)colpart, nbm, d, dw2, db1, db2, nblk_dw1);
-    if (aux != st) hipEventRecord(ev->join[1], aux);
+    if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
     // 4. dX rows = G . W1
     if (dx) {
         GemmParams r = {};
@@ -888,9 +889,10 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
         r.ldo = d;
         r.out_rows = rows;
         r.out_rows_n = (int)R;
-        launch_gemm(EPI_ROWS, r, st);
+        if (int rc = launch_gemm(EPI_ROWS, r, st)) return rc;
     }
-    if (aux != st) hipStreamWaitEvent(st, ev->join[1], 0);
+    if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[1], 0));
+#undef STAR_HIP
     STAR_LAUNCH_CHECK("star_scorer_bwd");
     return STAR_OK;
 }

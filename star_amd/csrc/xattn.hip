@@ -23,7 +23,6 @@
 // Masked logits are -inf (P and dS exactly 0), the running max starts at a finite sentinel.
 // Algorithmic FLOP per (b, layer): forward 4*L*k_b*d, backward 8*L*k_b*d (+ 4*L*k_b*d recompute).
 #include "common.h"
-#include <stdlib.h>
 
 namespace star {
 
@@ -94,6 +93,54 @@ __device__ __forceinline__ void tile_store(const TileRegs<HD, ROWS, NTH>& t, uin
     }
 }
 
+// ---- attention-probability dropout (my_transformer.py:595): counter-based keep mask, a pure function of
+// (seed, offset, b, h, query, key) as specified in star_nugget.h, regenerated by every backward kernel
+__device__ __forceinline__ uint32_t xa_mix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+template <bool DROP>
+struct Drop {
+    uint32_t k1, k2, thr;
+    float inv_keep;        // 1 / (1 - p_eff)
+    int Kn;
+    __device__ __forceinline__ Drop(const star_xattn_shape& s, int b, int h) {
+        if constexpr (DROP) {
+            uint64_t seed = s.seed, off = s.offset;
+            if (s.rng_state) {
+                seed = s.rng_state[0];
+                off = s.rng_state[1];
+            }
+            const uint32_t stream = 0x9e3779b9u * (uint32_t)(b * s.h + h + 1);
+            k1 = xa_mix((uint32_t)seed ^ xa_mix((uint32_t)(seed >> 32) ^ xa_mix((uint32_t)off ^ xa_mix((uint32_t)(off >> 32) + stream))));
+            k2 = xa_mix(k1 ^ 0x85ebca6bu);
+            const double t = (double)s.dropout_p * 4294967296.0;
+            thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+            inv_keep = (float)(1.0 / (1.0 - (double)thr * (1.0 / 4294967296.0)));
+            Kn = s.Kn;
+        }
+    }
+    __device__ __forceinline__ bool keep(int q, int key) const {
+        uint32_t x = k1 + (uint32_t)q * (uint32_t)Kn + (uint32_t)key;
+        x ^= x >> 16;
+        x *= 0x7feb352du;
+        x ^= k2;
+        x ^= x >> 15;
+        x *= 0x846ca68bu;
+        x ^= x >> 16;
+        return x >= thr;
+    }
+    // multiplier of an attention weight / of dP: 1/(1-p) where kept, 0 where dropped (1 without dropout)
+    __device__ __forceinline__ float km(int q, int key) const {
+        if constexpr (DROP) return keep(q, key) ? inv_keep : 0.f;
+        else return 1.f;
+    }
+};
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 8.0f;   // log2 units: the running max is only raised when a tile exceeds it by 2^8
@@ -112,7 +159,7 @@ struct FwdLds {
     static constexpr int BYTES = TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES;
 };
 
-template <int HD, int NG>
+template <int HD, int NG, bool DROP>
 __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ O,
@@ -145,6 +192,7 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * s.q_sr + ks * 16 + hf * 8);
 
+    const Drop<DROP> drop(s, b, h);
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     int kloop = kend;                                // keys any query of this workgroup can see
@@ -246,8 +294,10 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float p = __builtin_amdgcn_exp2f(sacc[sub][i] - m_run);
-                sacc[sub][i] = p;
                 psum += p;
+                // the softmax denominator is that of the undropped weights; only P V sees the mask
+                if constexpr (DROP) sacc[sub][i] = drop.keep(q, kbase + sub * 32 + crow(i, hf)) ? p : 0.f;
+                else sacc[sub][i] = p;
             }
         l_run += psum;
 
@@ -295,7 +345,8 @@ __global__ __launch_bounds__(NG * 256) void xattn_fwd_kernel(
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (DROP) inv *= drop.inv_keep;
     if (q < s.L) {
         __bf16* orow = O + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh + (int64_t)q * s.o_sr;
 #pragma unroll
@@ -324,7 +375,7 @@ struct DqLds {
     static constexpr int BYTES = TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES;
 };
 
-template <int HD, int NG>
+template <int HD, int NG, bool DROP>
 __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
@@ -371,6 +422,7 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
     if (grp == 0 && hf == 0 && q < s.L) delta[((int64_t)b * s.h + h) * s.L + q] = my_delta;
     const float my_lse2 = lse[((int64_t)b * s.h + h) * s.L + qc] * LOG2E;
 
+    const Drop<DROP> drop(s, b, h);
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     int kloop = kend;
@@ -435,7 +487,8 @@ __global__ __launch_bounds__(NG * 256) void xattn_bwd_dq_kernel(
                 for (int j = 0; j < 4; ++j) {
                     const int i = g * 4 + j;
                     float p = __builtin_amdgcn_exp2f(sacc[i] * scale2 + bb[j] - my_lse2);
-                    sacc[i] = p * (pacc[i] - my_delta);
+                    if constexpr (DROP) sacc[i] = p * (pacc[i] * drop.km(q, kbase + sub * 32 + crow(i, hf)) - my_delta);
+                    else sacc[i] = p * (pacc[i] - my_delta);
                 }
             }
             if (need_mask) {
@@ -586,7 +639,7 @@ __device__ __forceinline__ void ring_stage(uint8_t* smem, const __bf16* Kb, int6
     }
 }
 
-template <int HD, bool HAS_BIAS>
+template <int HD, bool HAS_BIAS, bool DROP>
 __global__ __launch_bounds__(512) void xattn_bwd_dq_ring_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
@@ -610,6 +663,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_dq_ring_kernel(
     const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
     const float* bias_row = HAS_BIAS ? bias + (int64_t)b * s.bias_len : zero_bias;
     const int bias_len = HAS_BIAS ? s.bias_len : 0;
+    const Drop<DROP> drop(s, b, h);
 
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
@@ -730,7 +784,9 @@ __global__ __launch_bounds__(512) void xattn_bwd_dq_ring_kernel(
                     for (int j = 0; j < 4; ++j) {
                         const float c = HAS_BIAS ? __builtin_fmaf(bb[t][j], LOG2E, -my_lse2) : -my_lse2;
                         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][j], scale2, c));
-                        df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
+                        if constexpr (DROP)
+                            df[4 * t + j] = (__bf16)(p * (pacc[t][j] * drop.km(q, kb0 + 16 * t + 4 * g + j) - my_delta));
+                        else df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
                     }
             } else {
 #pragma unroll
@@ -741,7 +797,8 @@ __global__ __launch_bounds__(512) void xattn_bwd_dq_ring_kernel(
                         const float bj = (HAS_BIAS && key < bias_len) ? bb[t][j] * LOG2E : 0.f;
                         float p = __builtin_amdgcn_exp2f(sacc[t][j] * scale2 + bj - my_lse2);
                         p = (key < klim) ? p : 0.f;
-                        df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
+                        if constexpr (DROP) df[4 * t + j] = (__bf16)(p * (pacc[t][j] * drop.km(q, key) - my_delta));
+                        else df[4 * t + j] = (__bf16)(p * (pacc[t][j] - my_delta));
                     }
             }
             xa_wait_lds();
@@ -780,7 +837,7 @@ struct DkvRegLds {
     static constexpr int BYTES = 2 * QB * PT + 2 * QB * 4 + V_BYTES;
 };
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void xattn_bwd_dkv_reg_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -812,6 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool key_ok = key < kend;
     const bool wg_live = kb0 < kend;
     const float scale2 = s.scale * LOG2E;
+    const Drop<DROP> drop(s, b, h);
 
     // K / V fragments of this lane's key (rows past Kn are clamped: their probabilities are masked to 0)
     bf16x8 kfr[KS], vfr[V_LDS ? 1 : KS];
@@ -899,7 +957,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const bool vis = key_ok && (qq < s.L) && (s.ilk_diag < 0 || key <= qq + s.ilk_diag);
                         p = vis ? p : 0.f;
                     }
-                    const float ds = p * (pacc[i] - dd[j]);
+                    float ds;
+                    if constexpr (DROP) {
+                        const float km = drop.km(q0 + crow(i, hf), key);
+                        ds = p * (pacc[i] * km - dd[j]);
+                        p *= km;                                    // dV sees the dropped, rescaled weights
+                    } else {
+                        ds = p * (pacc[i] - dd[j]);
+                    }
                     sacc[i] = p;
                     pacc[i] = ds;
                     db += ds;
@@ -965,7 +1030,7 @@ struct DkvSmall {
     }
 };
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -997,6 +1062,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     const float scale2 = s.scale * LOG2E;
+    const Drop<DROP> drop(s, b, h);
 
     const int ngroups = (s.Kn + 15) >> 4;
     const int gstride = gridDim.x * C::WAVES;
@@ -1129,7 +1195,14 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
                         const int qq = q0 + 16 * t + 4 * g + j;
                         float p = __builtin_amdgcn_exp2f(sacc[t][j] * scale2 + my_bias2 - ll[t][j]);
                         p = (qq >= qmin && qq < s.L) ? p : 0.f;
-                        const float ds = p * (pacc[t][j] - dd[t][j]);
+                        float ds;
+                        if constexpr (DROP) {
+                            const float km = drop.km(qq, key);
+                            ds = p * (pacc[t][j] * km - dd[t][j]);
+                            p *= km;
+                        } else {
+                            ds = p * (pacc[t][j] - dd[t][j]);
+                        }
                         db += ds;
                         pf[4 * t + j] = (__bf16)p;
                         df[4 * t + j] = (__bf16)ds;
@@ -1222,7 +1295,7 @@ __device__ __forceinline__ void xa_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ O, const __bf16* __restrict__ dO, const float* __restrict__ lse,
@@ -1258,6 +1331,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     const float scale2 = s.scale * LOG2E;
+    const Drop<DROP> drop(s, b, h);
     const int ngroups = (s.Kn + 15) >> 4;
     const int nrounds = (s.Kn + F::KROWS - 1) / F::KROWS;
 
@@ -1411,8 +1485,15 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                 if (plain) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j], scale2, my_bias2 - ll[j]));
-                        const float ds = p * (pacc[j] - dd[j]);
+                        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j], scale2, my_bias2 - ll[j]));
+                        float ds;
+                        if constexpr (DROP) {
+                            const float km = drop.km(q0 + 16 * t + 4 * g + j, key);
+                            ds = p * (pacc[j] * km - dd[j]);
+                            p *= km;
+                        } else {
+                            ds = p * (pacc[j] - dd[j]);
+                        }
                         db += ds;
                         pf[4 * t + j] = (__bf16)p;
                         df[4 * t + j] = (__bf16)ds;
@@ -1425,7 +1506,14 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[j], scale2, my_bias2 - ll[j]));
                         const bool vis = (qq >= qmin) & (qq < s.L);
                         p = vis ? p : 0.f;
-                        const float ds = p * (pacc[j] - dd[j]);
+                        float ds;
+                        if constexpr (DROP) {
+                            const float km = drop.km(qq, key);
+                            ds = p * (pacc[j] * km - dd[j]);
+                            p *= km;
+                        } else {
+                            ds = p * (pacc[j] - dd[j]);
+                        }
                         db += ds;
                         pf[4 * t + j] = (__bf16)p;
                         df[4 * t + j] = (__bf16)ds;
@@ -1618,7 +1706,7 @@ __global__ __launch_bounds__(256) void xattn_dbias_sum_kernel(DbiasParts parts, 
 }
 
 // P[b,h,q,key] = exp(logit - lse): the optional attention-weights output (output_attentions)
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(XA_THREADS) void xattn_probs_kernel(const __bf16* __restrict__ Q, const __bf16* __restrict__ K,
                                                                  const float* __restrict__ bias,
                                                                  const int32_t* __restrict__ key_len,
@@ -1635,25 +1723,15 @@ __global__ __launch_bounds__(XA_THREADS) void xattn_probs_kernel(const __bf16* _
     int kend = s.Kn;
     if (key_len) kend = min(kend, key_len[b]);
     const float l = lse[row];
+    const Drop<DROP> drop(s, b, h);
     for (int key = lane; key < s.Kn; key += 64) {
         const __bf16* krow = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh + (int64_t)key * s.k_sr;
         float acc = 0.f;
         for (int n = 0; n < HD; ++n) acc += (float)qrow[n] * (float)krow[n];
         const bool vis = (key < kend) && (s.ilk_diag < 0 || key <= q + s.ilk_diag);
         const float bj = (bias && key < s.bias_len) ? bias[(int64_t)b * s.bias_len + key] : 0.f;
-        P[row * s.Kn + key] = vis ? __expf(acc * s.scale + bj - l) : 0.f;
+        P[row * s.Kn + key] = vis ? __expf(acc * s.scale + bj - l) * drop.km(q, key) : 0.f;
     }
-}
-
-// hipFuncSetAttribute costs tens of microseconds on the host: do it once per kernel and device
-static bool reserve_lds(const void* fn, int bytes, bool* done) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    dev &= 63;
-    if (done[dev]) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-    done[dev] = true;
-    return true;
 }
 
 static int check_shape(const star_xattn_shape* s, const char* who) {
@@ -1667,64 +1745,68 @@ static int check_shape(const star_xattn_shape* s, const char* who) {
                      (s->q_sh % 8 == 0) && (s->k_sh % 8 == 0) && (s->v_sh % 8 == 0) && (s->o_sh % 8 == 0),
                  "%s: strides must be multiples of 8 elements (16-byte rows)", who);
     STAR_REQUIRE(s->bias_len >= 0 && s->bias_len <= s->Kn, "%s: bias_len %d not in [0, Kn=%d]", who, s->bias_len, s->Kn);
+    STAR_REQUIRE(s->dropout_p >= 0.f && s->dropout_p < 1.f, "%s: dropout_p %g not in [0, 1)", who, (double)s->dropout_p);
+    STAR_REQUIRE((int64_t)s->L * s->Kn < (1ll << 32), "%s: L*Kn exceeds the 32-bit dropout counter", who);
     return STAR_OK;
 }
 
-template <int HD, int NG>
+#define XA_RESERVE(fn, bytes, who)                                                          \
+    do {                                                                                    \
+        static DevOnce once_;                                                               \
+        if (!reserve_lds_once(once_, (const void*)(fn), (bytes))) {                         \
+            set_error("%s: cannot reserve %d bytes of LDS", who, (int)(bytes));             \
+            return STAR_ERR_LAUNCH;                                                         \
+        }                                                                                   \
+    } while (0)
+
+template <int HD, int NG, bool DROP>
 static int launch_fwd_ng(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
                          const star_xattn_shape* s, void* o, float* lse, hipStream_t st) {
     const int smem = FwdLds<HD, NG>::BYTES;
-    static bool done[64] = {};
-    if (!reserve_lds((const void*)xattn_fwd_kernel<HD, NG>, smem, done)) {
-        set_error("star_xattn_fwd: cannot reserve %d bytes of LDS", smem);
-        return STAR_ERR_LAUNCH;
-    }
+    XA_RESERVE((xattn_fwd_kernel<HD, NG, DROP>), smem, "star_xattn_fwd");
     dim3 grid(cdiv(s->L, 128), s->h, s->B);
-    hipLaunchKernelGGL((xattn_fwd_kernel<HD, NG>), grid, dim3(NG * 256), smem, st, (const __bf16*)q, (const __bf16*)k,
-                       (const __bf16*)v, bias, key_len, *s, (__bf16*)o, lse);
+    hipLaunchKernelGGL((xattn_fwd_kernel<HD, NG, DROP>), grid, dim3(NG * 256), smem, st, (const __bf16*)q,
+                       (const __bf16*)k, (const __bf16*)v, bias, key_len, *s, (__bf16*)o, lse);
     return STAR_OK;
 }
 
-template <int HD>
+template <int HD, bool DROP>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
                       const star_xattn_shape* s, void* o, float* lse, float* p_out, hipStream_t st) {
     // more than one 64-key tile: split the keys over two wave groups (two waves per SIMD)
-    static const char* force = getenv("STAR_XA_NG");
-    const bool two = force ? (force[0] == '2') : (s->Kn > KT);
-    int rc = two ? launch_fwd_ng<HD, 2>(q, k, v, bias, key_len, s, o, lse, st)
-                 : launch_fwd_ng<HD, 1>(q, k, v, bias, key_len, s, o, lse, st);
+    const int force = test_override(STAR_OVR_XA_NG);
+    const bool two = force ? (force == 2) : (s->Kn > KT);
+    int rc = two ? launch_fwd_ng<HD, 2, DROP>(q, k, v, bias, key_len, s, o, lse, st)
+                 : launch_fwd_ng<HD, 1, DROP>(q, k, v, bias, key_len, s, o, lse, st);
     if (rc) return rc;
     if (p_out) {
         const int64_t rows = (int64_t)s->B * s->h * s->L;
-        hipLaunchKernelGGL(xattn_probs_kernel<HD>, dim3(cdiv(rows, 4)), dim3(XA_THREADS), 0, st, (const __bf16*)q,
-                           (const __bf16*)k, bias, key_len, (const float*)lse, *s, p_out);
+        hipLaunchKernelGGL((xattn_probs_kernel<HD, DROP>), dim3(cdiv(rows, 4)), dim3(XA_THREADS), 0, st,
+                           (const __bf16*)q, (const __bf16*)k, bias, key_len, (const float*)lse, *s, p_out);
     }
     return STAR_OK;
 }
 
-template <int HD, int NG>
+template <int HD, int NG, bool DROP>
 static int launch_bwd_ng(const void* q, const void* k, const void* v, const void* o, const void* do_,
                          const float* lse, const float* bias, const int32_t* key_len, const star_xattn_shape* s,
                          void* dq, void* dk, void* dv, float* delta, float* dbias_part, hipStream_t st) {
     const int smem_dq = DqLds<HD, NG>::BYTES;
-    static const char* dq_force = getenv("STAR_XA_DQ");        // "gen" = always the general variant (A/B runs)
-    static const char* bwd_force = getenv("STAR_XA_BWD");      // "split" = never the fused kernel, "fused" = whenever legal
+    // test-only switches (star_test_override): force a kernel variant for A/B runs and coverage
+    const bool dq_gen = test_override(STAR_OVR_XA_DQ) == 1;
+    const bool dkv_gen = test_override(STAR_OVR_XA_DKV) == 1;
+    const int bwd_force = test_override(STAR_OVR_XA_BWD);      // 1 = never the fused kernel, 2 = whenever legal
     if constexpr (HD == 64 || HD == 128) {
-        static const char* dkv_force0 = getenv("STAR_XA_DKV");
-        const bool fused_ok = s->L <= BwdFused<HD>::QROWS && !dq_force && !dkv_force0;
+        const bool fused_ok = s->L <= BwdFused<HD>::QROWS && !dq_gen && !dkv_gen;
         // measured at configs[1]'s shape from B = 1 to 128: the fused kernel wins at every batch size (K = 375: 3 rounds);
         // only few (batch, head) pairs with MANY key rounds are left to the split pair, whose dK/dV kernel spreads
         // the key groups of one pair over several workgroups
         const int64_t bh_f = (int64_t)s->B * s->h;
-        const bool want = bwd_force ? (bwd_force[0] == 'f') : (bh_f >= 32 || s->Kn <= 512);
+        const bool want = bwd_force ? (bwd_force == 2) : (bh_f >= 32 || s->Kn <= 512);
         if (fused_ok && want) {
             const int smem_f = BwdFused<HD>::BYTES;
-            static bool done_fused[64] = {};
-            if (!reserve_lds((const void*)xattn_bwd_fused_small_kernel<HD>, smem_f, done_fused)) {
-                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_f);
-                return STAR_ERR_LAUNCH;
-            }
-            hipLaunchKernelGGL((xattn_bwd_fused_small_kernel<HD>), dim3(1, s->h, s->B), dim3(512), smem_f, st,
+            XA_RESERVE((xattn_bwd_fused_small_kernel<HD, DROP>), smem_f, "star_xattn_bwd");
+            hipLaunchKernelGGL((xattn_bwd_fused_small_kernel<HD, DROP>), dim3(1, s->h, s->B), dim3(512), smem_f, st,
                                (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
                                (const __bf16*)do_, lse, bias, key_len, *s, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv,
                                dbias_part);
@@ -1733,79 +1815,64 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
     }
     bool dq_done = false;
     if constexpr (HD == 64 || HD == 128) {
-        if (!dq_force) {
+        if (!dq_gen) {
             const int smem_s = Ring<HD>::BYTES;
             const bool hb = bias && s->bias_len > 0;
-            const void* kfn = hb ? (const void*)xattn_bwd_dq_ring_kernel<HD, true>
-                                 : (const void*)xattn_bwd_dq_ring_kernel<HD, false>;
-            static bool done_ring[2][64] = {};
-            if (!reserve_lds(kfn, smem_s, done_ring[hb ? 1 : 0])) {
-                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
-                return STAR_ERR_LAUNCH;
-            }
             // without a bias the DMA of the bias slot reads `lse` (any valid floats: never used)
-            if (hb)
-                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, true>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(512),
-                                   smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
-                                   (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len, *s, (__bf16*)dq);
-            else
-                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, false>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(512),
-                                   smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
-                                   (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len, *s, (__bf16*)dq);
+            if (hb) {
+                XA_RESERVE((xattn_bwd_dq_ring_kernel<HD, true, DROP>), smem_s, "star_xattn_bwd");
+                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, true, DROP>), dim3(cdiv(s->L, 128), s->h, s->B),
+                                   dim3(512), smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v,
+                                   (const __bf16*)o, (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len,
+                                   *s, (__bf16*)dq);
+            } else {
+                XA_RESERVE((xattn_bwd_dq_ring_kernel<HD, false, DROP>), smem_s, "star_xattn_bwd");
+                hipLaunchKernelGGL((xattn_bwd_dq_ring_kernel<HD, false, DROP>), dim3(cdiv(s->L, 128), s->h, s->B),
+                                   dim3(512), smem_s, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v,
+                                   (const __bf16*)o, (const __bf16*)do_, lse, delta, bias, (const float*)lse, key_len,
+                                   *s, (__bf16*)dq);
+            }
             dq_done = true;
         }
     }
     if (!dq_done) {
-        static bool done_dq[64] = {};
-        if (!reserve_lds((const void*)xattn_bwd_dq_kernel<HD, NG>, smem_dq, done_dq)) {
-            set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_dq);
-            return STAR_ERR_LAUNCH;
-        }
-        hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256), smem_dq,
-                           st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
+        XA_RESERVE((xattn_bwd_dq_kernel<HD, NG, DROP>), smem_dq, "star_xattn_bwd");
+        hipLaunchKernelGGL((xattn_bwd_dq_kernel<HD, NG, DROP>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(NG * 256),
+                           smem_dq, st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)o,
                            (const __bf16*)do_, lse, delta, bias, key_len, *s, (__bf16*)dq);
     }
-    static const char* dkv_force = getenv("STAR_XA_DKV");      // "gen" = always the general variant (A/B runs)
     if constexpr (HD == 64 || HD == 128) {
-        if (s->L <= DkvSmall<HD>::QROWS && !dkv_force) {
+        if (s->L <= DkvSmall<HD>::QROWS && !dkv_gen) {
             const int smem_s = DkvSmall<HD>::BYTES;
-            static bool done_small[64] = {};
-            if (!reserve_lds((const void*)xattn_bwd_dkv_small_kernel<HD>, smem_s, done_small)) {
-                set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_s);
-                return STAR_ERR_LAUNCH;
-            }
+            XA_RESERVE((xattn_bwd_dkv_small_kernel<HD, DROP>), smem_s, "star_xattn_bwd");
             // one workgroup (8 independent waves) per (batch, head); split the key groups over more workgroups
             // only when B*h alone cannot fill the chip
             const int ngroups = cdiv(s->Kn, 16);
             int nch = 1;
             const int64_t bh = (int64_t)s->B * s->h;
             if (bh < 192) nch = (int)min((int64_t)cdiv(ngroups, DkvSmall<HD>::WAVES), (256 + bh - 1) / bh);
-            hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD>), dim3(nch, s->h, s->B), dim3(512), smem_s, st,
+            hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD, DROP>), dim3(nch, s->h, s->B), dim3(512), smem_s, st,
                                (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
                                (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
             return STAR_OK;
         }
     }
     const int smem_r = DkvRegLds<HD>::BYTES;
-    static bool done_reg[64] = {};
-    if (!reserve_lds((const void*)xattn_bwd_dkv_reg_kernel<HD>, smem_r, done_reg)) {
-        set_error("star_xattn_bwd: cannot reserve %d bytes of LDS", smem_r);
-        return STAR_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL((xattn_bwd_dkv_reg_kernel<HD>), dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(256), smem_r, st,
+    XA_RESERVE((xattn_bwd_dkv_reg_kernel<HD, DROP>), smem_r, "star_xattn_bwd");
+    hipLaunchKernelGGL((xattn_bwd_dkv_reg_kernel<HD, DROP>), dim3(cdiv(s->Kn, KB), s->h, s->B), dim3(256), smem_r, st,
                        (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
                        (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
     return STAR_OK;
 }
 
-template <int HD>
+template <int HD, bool DROP>
 static int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                       const float* bias, const int32_t* key_len, const star_xattn_shape* s, void* dq, void* dk,
                       void* dv, float* delta, float* dbias_part, float* dbias, int accumulate, hipStream_t st) {
-    static const char* force = getenv("STAR_XA_NG");
-    const bool two = force ? (force[0] == '2') : true;
-    int rc = two ? launch_bwd_ng<HD, 2>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st)
-                 : launch_bwd_ng<HD, 1>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st);
+    const int force = test_override(STAR_OVR_XA_NG);
+    const bool two = force ? (force == 2) : true;
+    int rc = two ? launch_bwd_ng<HD, 2, DROP>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st)
+                 : launch_bwd_ng<HD, 1, DROP>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, st);
     if (rc) return rc;
     if (dbias && s->bias_len > 0)
         hipLaunchKernelGGL(xattn_dbias_reduce_kernel, dim3(cdiv(s->bias_len, 256), s->B), dim3(256), 0, st,
@@ -1823,11 +1890,15 @@ extern "C" int star_xattn_fwd(const void* q, const void* k, const void* v, const
     STAR_REQUIRE(q && k && v && o && lse, "star_xattn_fwd: null pointer");
     STAR_REQUIRE(!(bias == nullptr && s->bias_len > 0), "star_xattn_fwd: bias_len > 0 but bias is null");
     hipStream_t st = (hipStream_t)stream;
+    const bool drop = s->dropout_p > 0.f;
+#define XA_FWD(HD_) (drop ? launch_fwd<HD_, true>(q, k, v, bias, key_len, s, o, lse, p_out, st) \
+                          : launch_fwd<HD_, false>(q, k, v, bias, key_len, s, o, lse, p_out, st))
     switch (s->hd) {
-        case 64: rc = launch_fwd<64>(q, k, v, bias, key_len, s, o, lse, p_out, st); break;
-        case 96: rc = launch_fwd<96>(q, k, v, bias, key_len, s, o, lse, p_out, st); break;
-        default: rc = launch_fwd<128>(q, k, v, bias, key_len, s, o, lse, p_out, st); break;
+        case 64: rc = XA_FWD(64); break;
+        case 96: rc = XA_FWD(96); break;
+        default: rc = XA_FWD(128); break;
     }
+#undef XA_FWD
     if (rc) return rc;
     STAR_LAUNCH_CHECK("star_xattn_fwd");
     return STAR_OK;
@@ -1844,11 +1915,18 @@ extern "C" int star_xattn_bwd(const void* q, const void* k, const void* v, const
     STAR_REQUIRE(!(bias == nullptr && s->bias_len > 0), "star_xattn_bwd: bias_len > 0 but bias is null");
     STAR_REQUIRE(!(dbias && !dbias_part), "star_xattn_bwd: dbias requested without dbias_part scratch");
     hipStream_t st = (hipStream_t)stream;
+    const bool drop = s->dropout_p > 0.f;
+#define XA_BWD(HD_)                                                                                                \
+    (drop ? launch_bwd<HD_, true>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, dbias,     \
+                                  accumulate, st)                                                                  \
+          : launch_bwd<HD_, false>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, dbias,    \
+                                   accumulate, st))
     switch (s->hd) {
-        case 64: rc = launch_bwd<64>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, dbias, accumulate, st); break;
-        case 96: rc = launch_bwd<96>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, dbias, accumulate, st); break;
-        default: rc = launch_bwd<128>(q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, delta, dbias_part, dbias, accumulate, st); break;
+        case 64: rc = XA_BWD(64); break;
+        case 96: rc = XA_BWD(96); break;
+        default: rc = XA_BWD(128); break;
     }
+#undef XA_BWD
     if (rc) return rc;
     STAR_LAUNCH_CHECK("star_xattn_bwd");
     return STAR_OK;

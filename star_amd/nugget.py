@@ -40,8 +40,10 @@ class NuggetScorer(nn.Sequential):
         self.active_rows = ops.ActiveRows()
 
     def set_active_rows(self, rows: Optional[torch.Tensor]):
-        """Optional: frames (flattened b*T+t) that can receive a score gradient this step (None = all)."""
-        self.active_rows.rows = rows
+        """Optional, SINGLE-USE: frames (flattened b*T+t) that can receive a score gradient in the backward of the
+        most recent forward (or of the next one, when called before any forward); None = dense.  The hint is
+        consumed by that backward; every other forward/backward of this module runs dense (ops.ActiveRows)."""
+        self.active_rows.set(rows)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,T,d] -> [B,T,1]
         s = ops.scorer(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias, self.active_rows)
@@ -82,7 +84,8 @@ class NuggetOpsMixin:
                                rate=self.nugget_compress_rate, K=K, want_table=True)
 
     def resize(self, alphas, target_lengths, noise=0.0, threshold=1.0):
-        """w2v_simul.py:504-535.  noise must be 0 (the only value the reference ever passes)."""
+        """w2v_simul.py:504-535, differentiable w.r.t. alphas like the reference's (lm_cif_training sends the
+        lm_loss gradient through it).  noise must be 0 (the only value the reference ever passes)."""
         if noise != 0.0:
             raise NotImplementedError("resize: noise != 0 is never used by the reference and is not implemented")
         return ops.cif_resize(alphas, target_lengths, threshold=threshold)
@@ -108,8 +111,8 @@ class NuggetOpsMixin:
         """w2v_simul.py:196-220: ascending positions of the True entries, padded; -> (indices, max_valid, n)."""
         assert len(mask.shape) <= 2, f"Only supports 1D or 2D tensors - got {len(mask.shape)}."
         m2 = mask if mask.dim() == 2 else mask.unsqueeze(0)
-        # a fire scan over a 0/1 "alpha" fires exactly at the True positions
-        # (lengths = T+1: every frame counts, and the forced last-frame fire never triggers)
+        # a fire scan over a 0/1 "alpha" fires exactly at the True positions; lengths = T+1 (> T) makes every frame
+        # count and switches the forced last-frame fire off (star_cif_fire_scan keeps the length unclamped for that)
         idx, _, counts, mx, _ = ops.cif_fire_scan(m2.to(torch.float32), lengths=torch.full(
             (m2.shape[0],), m2.shape[1] + 1, dtype=torch.int32, device=m2.device))
         max_valid = int(mx.item())
@@ -136,8 +139,9 @@ class NuggetOpsMixin:
 # ------------------------------------------------------------------------------------------ a8
 def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
                       limit_cross_attn=False, scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
-                      layer_idx=0, key_lengths=None, output_attentions=False):
-    """MyGPT2Attention._attn for cross-attention (my_transformer.py:535-603), dropout p = 0.
+                      layer_idx=0, key_lengths=None, output_attentions=False, dropout_p=0.0, dropout_rng=None):
+    """MyGPT2Attention._attn for cross-attention (my_transformer.py:535-603); dropout_p is the probability of
+    `self.attn_dropout` (my_transformer.py:595; pass 0 in eval mode), applied inside the kernels.
 
     query [B,h,L,hd], key/value [B,h,K,hd]; attention_mask is the additive [B,1,1,K] encoder mask produced
     by invert_attention_mask (0 / finfo.min); scorer_logits [B,Kb<=K].  Returns (attn_output, attn_weights or
@@ -154,10 +158,11 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
     B, K = query.shape[0], key.shape[2]
     if scorer_logits is not None and scorer_logits.dim() == 3:
         # a per-layer view from share_scorer_logits(): the encoder mask is already folded in
-        if scorer_logits.shape[2] != K:
+        if scorer_logits.shape[2] > K:
             raise ValueError(f"shared scorer_logits cover {scorer_logits.shape[2]} keys but there are {K}")
         return ops.xattn(query, key, value, bias=scorer_logits, key_len=key_lengths,
-                         ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions)
+                         ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
+                         dropout_p=dropout_p, dropout_rng=dropout_rng)
     if attention_mask is not None:
         if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
             raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
@@ -166,11 +171,15 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
         s = scorer_logits.to(torch.float32)
         if s.shape[1] > K:
             raise ValueError(f"scorer_logits has {s.shape[1]} columns but there are only {K} keys")
-        if s.shape[1] < K:   # prefix-bias variant (my_transformer.py:114-125): zero-extend
-            s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
-        bias = s if bias is None else bias + s
+        if bias is None:
+            bias = s            # prefix-bias variant (my_transformer.py:114-125): the kernel takes bias_len <= K
+        else:
+            if s.shape[1] < K:
+                s = torch.nn.functional.pad(s, (0, K - s.shape[1]))   # the pad mask covers all K keys
+            bias = bias + s
     out, probs = ops.xattn(query, key, value, bias=bias, key_len=key_lengths,
-                           ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions)
+                           ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
+                           dropout_p=dropout_p, dropout_rng=dropout_rng)
     return out, probs
 
 
@@ -186,11 +195,11 @@ def share_scorer_logits(scorer_logits, n_layers: int, n_heads: int, attention_ma
     K = n_keys if n_keys is not None else (attention_mask.shape[-1] if attention_mask is not None else s.shape[1])
     if s.shape[1] > K:
         raise ValueError(f"scorer_logits has {s.shape[1]} columns but there are only {K} keys")
-    if s.shape[1] < K:
-        s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
     if attention_mask is not None:
         if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
             raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
+        if s.shape[1] < K:
+            s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
         s = attention_mask.reshape(B, K).to(torch.float32) + s
     return ops.share_bias(s, n_layers, n_heads)
 
@@ -218,9 +227,11 @@ class NuggetCrossAttention(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, layer_idx: int = 0, scale_attn_weights: bool = True,
                  scale_attn_by_inverse_layer_idx: bool = False, resid_pdrop: float = 0.0, attn_pdrop: float = 0.0):
         super().__init__()
-        # dropout on the attention probabilities (GPT2Config.attn_pdrop, 0.1 by default) is not implemented inside the
-        # fused core: refuse it in training rather than train silently without it
+        # dropout on the attention probabilities (GPT2Config.attn_pdrop, 0.1 in the reference's decoder config,
+        # w2v_asr.py:134-145; my_transformer.py:595) runs inside the fused core, in training mode only
         self.attn_pdrop = float(attn_pdrop)
+        if not 0.0 <= self.attn_pdrop < 1.0:
+            raise ValueError(f"attn_pdrop = {attn_pdrop} not in [0, 1)")
         if hidden_size % num_heads:
             raise ValueError("`embed_dim` must be divisible by num_heads")
         self.embed_dim, self.num_heads, self.head_dim = hidden_size, num_heads, hidden_size // num_heads
@@ -263,16 +274,14 @@ class NuggetCrossAttention(nn.Module):
               limit_cross_attn=False, output_attentions=False):
         return score_biased_attn(query, key, value, attention_mask, head_mask, scorer_logits, limit_cross_attn,
                                  self.scale_attn_weights, self.scale_attn_by_inverse_layer_idx, self.layer_idx,
-                                 output_attentions=output_attentions)
+                                 output_attentions=output_attentions,
+                                 dropout_p=self.attn_pdrop if self.training else 0.0)
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, use_cache=False, output_attentions=False,
                 scorer_logits=None, limit_cross_attn=False):
         if encoder_hidden_states is None:
             raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
-        if self.training and self.attn_pdrop > 0.0:
-            raise NotImplementedError(f"attn_pdrop = {self.attn_pdrop}: attention-probability dropout is not implemented "
-                                      "in the fused core; build the decoder config with attn_pdrop = 0")
         query = self._split_heads(self.q_attn(hidden_states))
         key, value = self._encoder_kv(encoder_hidden_states)
         if layer_past is not None:

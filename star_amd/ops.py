@@ -172,8 +172,8 @@ class _GatherRows(torch.autograd.Function):
 def gather_rows(src, idx):
     """dst[b,j] = src[b, idx[b,j]] for src [B,T,d] or [B,T]; idx -1 addresses the last frame."""
     _need_cuda(src, idx)
-    if src.dtype not in (torch.bfloat16, torch.float32, torch.float16):
-        raise TypeError(f"gather_rows: unsupported dtype {src.dtype}")
+    if src.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"gather_rows: unsupported dtype {src.dtype} (bf16 / fp32, forward and backward)")
     return _GatherRows.apply(src, idx.to(torch.int64))
 
 
@@ -257,15 +257,40 @@ def cif_quantity(scores, target_lengths, attn_mask=None, lengths=None, threshold
 
 
 # ----------------------------------------------------------------------------- a6
+class _CifResize(torch.autograd.Function):
+    """W2VSimulModel.resize (w2v_simul.py:504-535), noise = 0, with its gradient (needed by lm_cif_training,
+    w2v_simul.py:558; the nugget path detaches the output, w2v_simul.py:426)."""
+
+    @staticmethod
+    def forward(ctx, alphas, target_i32, threshold, max_rounds):
+        ctx.set_materialize_grads(False)
+        a = alphas.detach().to(torch.float32).contiguous()
+        B, T = a.shape
+        out = torch.empty_like(a)
+        fix = torch.empty((B,), dtype=torch.int32, device=a.device)
+        check(lib().star_cif_resize(ptr(a), ptr(target_i32), float(threshold), int(max_rounds), B, T, ptr(out),
+                                    ptr(fix), stream_ptr()), "star_cif_resize")
+        ctx.save_for_backward(a, target_i32, fix)
+        ctx.in_dtype = alphas.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        a, tl, fix = ctx.saved_tensors
+        B, T = a.shape
+        gd = g.to(torch.float32).contiguous()
+        da = torch.empty_like(a)
+        check(lib().star_cif_resize_bwd(ptr(a), ptr(tl), ptr(fix), ptr(gd), B, T, ptr(da), stream_ptr()),
+              "star_cif_resize_bwd")
+        return da.to(ctx.in_dtype), None, None, None
+
+
 def cif_resize(alphas, target_lengths, threshold: float = 1.0, max_rounds: int = 10):
-    """W2VSimulModel.resize (w2v_simul.py:504-535), noise = 0.  No gradient (the live call site detaches it)."""
+    """W2VSimulModel.resize (w2v_simul.py:504-535), noise = 0.  Differentiable w.r.t. alphas."""
     _need_cuda(alphas, target_lengths)
-    a = alphas.detach().to(torch.float32).contiguous()
-    B, T = a.shape
-    out = torch.empty_like(a)
-    check(lib().star_cif_resize(ptr(a), ptr(target_lengths.to(torch.int32).contiguous()), float(threshold),
-                                int(max_rounds), B, T, ptr(out), stream_ptr()), "star_cif_resize")
-    return out
+    return _CifResize.apply(alphas, target_lengths.to(torch.int32).contiguous(), float(threshold), int(max_rounds))
 
 
 # ----------------------------------------------------------------------------- a7
@@ -307,13 +332,35 @@ def cif_block_mask(idx, counts, attn_mask=None, lengths=None, T: Optional[int] =
 
 # ----------------------------------------------------------------------------- a1
 class ActiveRows:
-    """Mutable hint shared between the scorer and the selector: the frames (flattened b*T+t, int32) whose
-    dscore can be non-zero.  In the non-streaming path only the <= K selected frames per utterance get a
-    gradient (loss = lm_loss only, w2v_asr.py:580-581), so the scorer backward runs on those rows alone.
-    Leave .rows = None for a dense backward."""
+    """Hint shared between the selector and the scorer: the frames (flattened b*T+t, int32) whose dscore can be
+    non-zero in the NEXT forward/backward of the scorer.  In the non-streaming path only the <= K selected frames
+    per utterance get a gradient (loss = lm_loss only, w2v_asr.py:580-581), so the scorer backward runs on those
+    rows alone.  The hint is SINGLE-USE: it is bound to the scores tensor of the forward that precedes set() (or to
+    the next forward when none has run yet) and consumed by that forward's backward; any other forward/backward of
+    the same scorer (a dense regulariser, the simultaneous path, a later step that forgets to set it) runs dense.
+    dscores outside the listed rows are NOT propagated: list every frame that can receive a gradient."""
 
     def __init__(self):
         self.rows = None
+        self._owner = None          # id of the forward (a counter) the rows belong to
+        self._last_forward = 0
+
+    def set(self, rows):
+        self.rows = rows
+        self._owner = self._last_forward if (rows is not None and self._last_forward > 0) else None
+
+    def _begin_forward(self) -> int:
+        self._last_forward += 1
+        if self.rows is not None and self._owner is None:
+            self._owner = self._last_forward        # set() came before the forward
+        return self._last_forward
+
+    def _take(self, forward_id: int):
+        """Rows for the backward of forward `forward_id`, or None (dense).  Consumes the hint."""
+        if self.rows is None or self._owner != forward_id:
+            return None
+        rows, self.rows, self._owner = self.rows, None, None
+        return rows
 
 
 # ----------------------------------------------------------------------------- 8f-2
@@ -374,16 +421,24 @@ def cif_aggregate(alphas, s, threshold: float = 1.0, cap: Optional[int] = None):
 
 
 _AUX_STREAMS = {}
+_AUX_LOCK = __import__("threading").Lock()
 
 
 def _aux_stream(dev):
-    """Second stream handed to star_scorer_bwd for its memory-bound helpers (one per device and calling stream)."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    st = _AUX_STREAMS.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=dev)
-        _AUX_STREAMS[key] = st
-    return st
+    """Second stream + the four fork/join events handed to star_scorer_bwd (one set per device, calling stream and
+    calling thread: autograd runs backward on its own thread, and two threads must not share events)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, __import__("threading").get_ident())
+    with _AUX_LOCK:
+        ent = _AUX_STREAMS.get(key)
+        if ent is None:
+            st = torch.cuda.Stream(device=dev)
+            evs = [torch.cuda.Event(enable_timing=False) for _ in range(4)]
+            for e in evs:
+                e.record(st)                      # torch creates the hipEvent_t lazily, at the first record
+            arr = (_lib.C.c_void_p * 4)(*[e.cuda_event for e in evs])
+            ent = (st, evs, arr)
+            _AUX_STREAMS[key] = ent
+    return ent
 
 
 class _Scorer(torch.autograd.Function):
@@ -414,6 +469,7 @@ class _Scorer(torch.autograd.Function):
                                     wsb, stream_ptr()), "star_scorer_fwd")
         ctx.save_for_backward(xb, w1b, w1t, b1f, w2f)
         ctx.hint = hint
+        ctx.forward_id = hint._begin_forward() if hint is not None else 0
         ctx.x_shape = x.shape
         ctx.x_dtype = x.dtype
         ctx.w_dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
@@ -429,7 +485,9 @@ class _Scorer(torch.autograd.Function):
         N, d = xb.shape
         dev = xb.device
         ds = g.to(torch.float32).contiguous().view(-1)
-        rows = ctx.hint.rows if ctx.hint is not None else None
+        rows = ctx.hint._take(ctx.forward_id) if ctx.hint is not None else None
+        if rows is not None and rows.numel() > N:
+            raise ValueError(f"scorer backward: {rows.numel()} active rows for {N} frames (stale hint?)")
         if rows is None:
             rows = torch.arange(N, dtype=torch.int32, device=dev)
         rows = rows.to(torch.int32).contiguous().view(-1)
@@ -447,7 +505,8 @@ class _Scorer(torch.autograd.Function):
         aux = _aux_stream(dev) if torch.cuda.is_current_stream_capturing() else None
         check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1t), ptr(b1f), ptr(w2f), ptr(ds), ptr(rows), R, N, d,
                                     ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0, ptr(ws), wsb, stream_ptr(),
-                                    aux.cuda_stream if aux is not None else None), "star_scorer_bwd")
+                                    aux[0].cuda_stream if aux is not None else None,
+                                    aux[2] if aux is not None else None), "star_scorer_bwd")
         t1, t2, t3, t4 = ctx.w_dtypes
         gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
         return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None)
@@ -460,7 +519,36 @@ def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None):
 
 
 # ----------------------------------------------------------------------------- a8
-def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale):
+class _DropoutState:
+    """Per-device {seed, offset} pair for attention dropout, kept ON THE DEVICE so that a step captured in a HIP
+    graph draws a fresh mask at every replay: every forward snapshots the pair (the backward regenerates the mask
+    from the snapshot) and advances the offset with a stream-ordered add.  Seeded from torch's CUDA generator
+    (torch.manual_seed / torch.cuda.manual_seed re-seed it)."""
+    _states = {}
+    _forced_seed = None
+
+    @classmethod
+    def next(cls, dev):
+        seed = cls._forced_seed if cls._forced_seed is not None else torch.cuda.initial_seed()
+        ent = cls._states.get(dev.index)
+        if ent is None or ent[0] != seed:
+            st = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+            ent = (seed, st)
+            cls._states[dev.index] = ent
+        st = ent[1]
+        snap = st.clone()
+        st[1:].add_(1)
+        return snap
+
+
+def reset_dropout_state(seed: Optional[int] = None):
+    """Restart the attention-dropout stream of every device: from `seed`, or (None) from torch's CUDA seed
+    (torch.manual_seed / torch.cuda.manual_seed with a NEW value re-seed it on their own)."""
+    _DropoutState._forced_seed = None if seed is None else int(seed)
+    _DropoutState._states.clear()
+
+
+def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale, dropout=None):
     B, h, L, hd = q.shape
     Kn = k.shape[2]
     for t, name in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
@@ -475,6 +563,14 @@ def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale):
     s.v_sb, s.v_sh, s.v_sr = v.stride(0), v.stride(1), v.stride(2)
     s.o_sb, s.o_sh, s.o_sr = o.stride(0), o.stride(1), o.stride(2)
     s.bias_len, s.ilk_diag, s.scale = int(bias_len), int(ilk_diag), float(scale)
+    s.dropout_p, s.seed, s.offset, s.rng_state = 0.0, 0, 0, None
+    if dropout is not None:
+        p, rng = dropout
+        s.dropout_p = float(p)
+        if isinstance(rng, torch.Tensor):
+            s.rng_state = rng.data_ptr()
+        else:
+            s.seed, s.offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFFFFFFFFFF
     return s
 
 
@@ -491,7 +587,7 @@ class _XAttn(torch.autograd.Function):
     """softmax(QK^T*scale + ILK + bias) V with d(bias) = sum_{h,i} dS (my_transformer.py:535-603)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs):
+    def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs, dropout_p, dropout_rng):
         ctx.set_materialize_grads(False)
         in_dtype = q.dtype
         qb, kb, vb = (t.detach() if t.dtype == torch.bfloat16 else t.detach().to(torch.bfloat16) for t in (q, k, v))
@@ -512,11 +608,17 @@ class _XAttn(torch.autograd.Function):
         ctx.bias_per_head = per_head
         kl = None if key_len is None else key_len.to(torch.int32).contiguous()
         probs = torch.empty((B, h, L, kb.shape[2]), dtype=torch.float32, device=dev) if need_probs else None
-        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
+        dropout = None
+        if dropout_p > 0.0:
+            # (seed, offset) host integers (reproducible tests) or the per-device state advanced on the stream
+            rng = dropout_rng if dropout_rng is not None else _DropoutState.next(dev)
+            dropout = (float(dropout_p), rng)
+        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale, dropout)
         check(lib().star_xattn_fwd(ptr(qb), ptr(kb), ptr(vb), ptr(bias_f), ptr(kl), s, ptr(o), ptr(lse), ptr(probs),
                                    stream_ptr()), "star_xattn_fwd")
         ctx.save_for_backward(qb, kb, vb, o, lse, bias_f, kl)
         ctx.cfg = (ilk_diag, scale, bias_len)
+        ctx.dropout = dropout
         ctx.in_dtype = in_dtype
         ctx.bias_dtype = None if bias is None else bias.dtype
         out = o if in_dtype == torch.bfloat16 else o.to(in_dtype)
@@ -528,7 +630,7 @@ class _XAttn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g_probs):
         if g is None:
-            return None, None, None, None, None, None, None, None
+            return (None,) * 10
         qb, kb, vb, o, lse, bias_f, kl = ctx.saved_tensors
         ilk_diag, scale, bias_len = ctx.cfg
         B, h, L, hd = qb.shape
@@ -549,7 +651,7 @@ class _XAttn(torch.autograd.Function):
             part = torch.empty((B, h, Kn), dtype=torch.float32, device=dev)
             if not ctx.bias_per_head:
                 dbias = torch.empty((B, bias_len), dtype=torch.float32, device=dev)
-        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale)
+        s = _xattn_shape(qb, kb, vb, o, bias_len, ilk_diag, scale, ctx.dropout)
         check(lib().star_xattn_bwd(ptr(qb), ptr(kb), ptr(vb), ptr(o), ptr(go), ptr(lse), ptr(bias_f), ptr(kl), s,
                                    ptr(dq), ptr(dk), ptr(dv), ptr(delta), ptr(part), ptr(dbias), 0, stream_ptr()),
               "star_xattn_bwd")
@@ -560,7 +662,7 @@ class _XAttn(torch.autograd.Function):
             dbias = part if bias_len == Kn else part[:, :, :bias_len]
         if dbias is not None and ctx.bias_dtype != torch.float32:
             dbias = dbias.to(ctx.bias_dtype)
-        return dq, dk, dv, dbias, None, None, None, None
+        return dq, dk, dv, dbias, None, None, None, None, None, None
 
 
 class _TypeEmbedAdd(torch.autograd.Function):
@@ -660,11 +762,29 @@ def share_bias(bias, n_layers: int, n_heads: int):
 
 
 def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[float] = None,
-          need_probs: bool = False):
-    """q [B,h,L,hd]; k, v [B,h,Kn,hd]; bias [B,bias_len<=Kn] fp32 added to every query's logits; key_len [B]
-    masks keys >= key_len[b]; ilk_diag >= 0 enables the infinite-lookback mask (key j visible iff j <= i+diag).
-    Returns (O [B,h,L,hd] (memory order [B,L,h,hd]), P or None)."""
+          need_probs: bool = False, dropout_p: float = 0.0, dropout_rng=None):
+    """q [B,h,L,hd]; k, v [B,h,Kn,hd]; bias [B,bias_len<=Kn] fp32 added to every query's logits (keys past
+    bias_len get 0: the prefix-bias variant, my_transformer.py:114-125); key_len [B] masks keys >= key_len[b];
+    ilk_diag >= 0 enables the infinite-lookback mask (key j visible iff j <= i+diag).
+    dropout_p > 0: attention-probability dropout (my_transformer.py:595) with the counter-based mask specified in
+    star_nugget.h; dropout_rng = (seed, offset) host integers for a reproducible mask, a device int64[2] tensor, or
+    None to draw from the per-device state seeded by torch's generator.
+    Returns (O [B,h,L,hd] (memory order [B,L,h,hd]), P or None); P holds the dropped, rescaled weights."""
     _need_cuda(q, k, v, bias, key_len)
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
-    return _XAttn.apply(q, k, v, bias, key_len, int(ilk_diag), float(scale), bool(need_probs))
+    if not 0.0 <= dropout_p < 1.0:
+        raise ValueError(f"xattn: dropout_p = {dropout_p} not in [0, 1)")
+    return _XAttn.apply(q, k, v, bias, key_len, int(ilk_diag), float(scale), bool(need_probs), float(dropout_p),
+                        dropout_rng)
+
+
+def test_override(which: int, value: int) -> int:
+    """TEST-ONLY: force a kernel variant (star_test_override in star_nugget.h); returns the previous value."""
+    rc = lib().star_test_override(int(which), int(value))
+    if rc < 0:
+        check(rc, "star_test_override")
+    return rc
+
+
+OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG = 0, 1, 2, 3

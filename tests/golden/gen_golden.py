@@ -410,8 +410,92 @@ def gen_type_embed():
              out=out, gout=gout, dx=x.grad, demb=emb.weight.grad)
 
 
+# ------------------------------------------------------------------ round 2 additions
+def gen_resize_grad():
+    """resize (w2v_simul.py:504-535) WITH its autograd gradient, as lm_cif_training differentiates it (w2v_simul.py:558):
+    alphas = sigmoid(scores) * mask with requires_grad, a random cotangent on the resized alphas."""
+    sim = w2v_simul.W2VSimulModel
+    me = SimpleNamespace()
+    g = torch.Generator().manual_seed(61)
+    cases = [("plain", torch.randn(4, 48, generator=g), [48, 40, 31, 17], [6, 5, 4, 3])]
+    s = torch.randn(5, 24, generator=g)
+    s[0, 3] = 6.0
+    s[1, :] = -4.0
+    s[1, 5] = 5.0
+    s[1, 9] = 4.0
+    s[2, 2] = 8.0
+    s[4, 7] = 9.0
+    s[4, 11] = 7.5
+    cases.append(("fixup", s, [24, 20, 6, 12, 16], [9, 7, 5, 4, 11]))
+    for name, scores, lengths, tgt in cases:
+        t = scores.shape[1]
+        mask = len_mask(lengths, t)
+        tl = torch.tensor(tgt)
+        alphas = (torch.sigmoid(scores) * mask).detach().requires_grad_()
+        resized = sim.resize(me, alphas, tl)
+        gout = torch.randn(resized.shape, generator=g)
+        (resized * gout).sum().backward()
+        save("resize_grad_" + name, alphas=alphas, lengths=np.array(lengths), target_lengths=tl, resized=resized,
+             gout=gout, dalphas=alphas.grad)
+
+
+def gen_valid_indices():
+    """get_valid_mask_indices (w2v_simul.py:196-220) on masks whose last element is False / True, 1-D and 2-D, with
+    the default and a non-default padding value (a forced last-frame fire must not leak in)."""
+    sim = w2v_simul.W2VSimulModel
+    g = torch.Generator().manual_seed(67)
+    m2 = torch.rand(5, 23, generator=g) < 0.3
+    m2[0, -1] = False
+    m2[1, -1] = True
+    m2[2, :] = False
+    m2[2, 4] = True
+    m2[3, -3:] = False
+    m1 = torch.rand(17, generator=g) < 0.4
+    m1[-1] = False
+    out = {}
+    for tag, m, pv in (("a", m2, -1), ("b", m2, -7), ("c", m1, -1), ("d", m1, 99)):
+        idx, kmax, n = sim.get_valid_mask_indices(m, padding_value=pv)
+        out[f"mask_{tag}"], out[f"pad_{tag}"], out[f"idx_{tag}"] = m, np.int64(pv), idx
+        out[f"kmax_{tag}"], out[f"n_{tag}"] = np.int64(kmax), n
+    save("valid_indices", **out)
+
+
+def gen_xattn_drop():
+    """MyGPT2Attention._attn (my_transformer.py:535-603) with attention-probability dropout (:595) under a GIVEN keep
+    mask: `attn_dropout` is replaced by a module that multiplies by mask / (1 - p), which is what nn.Dropout(p) does
+    with the mask it draws.  Pins where the mask enters the forward and the gradients."""
+    att = my_transformer.MyGPT2Attention
+    g = torch.Generator().manual_seed(71)
+
+    class GivenDropout(torch.nn.Module):
+        def __init__(self, mask, p):
+            super().__init__()
+            self.mask, self.p = mask, p
+
+        def forward(self, w):
+            return w * self.mask / (1.0 - self.p)
+
+    for name, b, h, lq, lk, hd, klen, ilk, p in (("drop_a", 2, 2, 6, 9, 8, [9, 5], False, 0.25),
+                                                 ("drop_ilk", 2, 3, 7, 10, 16, [10, 8], True, 0.1)):
+        q = torch.randn(b, h, lq, hd, generator=g).requires_grad_()
+        k = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        v = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        sc = torch.randn(b, lk, generator=g).requires_grad_()
+        gout = torch.randn(b, h, lq, hd, generator=g)
+        keep = (torch.rand(b, h, lq, lk, generator=g) >= p).to(torch.float32)
+        kmask = len_mask(klen, lk)
+        add = (1.0 - kmask[:, None, None, :].to(torch.float32)) * torch.finfo(torch.float32).min
+        me = SimpleNamespace(scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
+                             is_cross_attention=True, layer_idx=0, attn_dropout=GivenDropout(keep, p))
+        o, pw = att._attn(me, q, k, v, add, None, sc, limit_cross_attn=ilk)
+        (o * gout).sum().backward()
+        save("xattn_" + name, q=q, k=k, v=v, scores=sc, key_lengths=np.array(klen), ilk=np.array(ilk),
+             keep=keep, drop_p=np.float32(p), gout=gout, o=o, p=pw, dq=q.grad, dk=k.grad, dv=v.grad, dscores=sc.grad)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed):
+    for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed, gen_resize_grad,
+               gen_valid_indices, gen_xattn_drop):
         if not only or fn.__name__ in only:
             fn()

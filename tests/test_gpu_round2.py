@@ -1,0 +1,335 @@
+"""GPU parity, round-2 additions (all through the C ABI): attention-probability dropout, the prefix-bias variant
+(bias_len < Kn), resize backward, get_valid_mask_indices, gather edge cases, the single-use active-row hint.
+
+Bars as in tests/test_gpu_parity.py: integer results bit-exact; bf16-MFMA results against the fp32 oracle on the same
+bf16-rounded inputs at 2e-2 of the tensor scale; fp32 scalar paths rtol 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nugget_oracle as orc
+from tests.test_oracle_golden import lmask, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from star_amd import ops as o
+    return o
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def close(a, b, what, tol=2e-2):
+    a = a.detach().float().cpu().numpy()
+    b = b.detach().float().cpu().numpy()
+    scale = np.abs(b).max()
+    assert np.abs(a - b).max() <= tol * scale + 1e-6, f"{what}: max err {np.abs(a - b).max()} scale {scale}"
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r1 (high)
+def test_get_valid_mask_indices_golden():
+    """Every returned value of the mirrored method against the reference golden (w2v_simul.py:196-220): masks whose
+    last element is False must not get a forced last-frame index; 1-D and 2-D; non-default padding value."""
+    from star_amd.nugget import NuggetOpsMixin
+    g = load("valid_indices")
+    for tag in "abcd":
+        m = dev(g[f"mask_{tag}"])
+        idx, kmax, n = NuggetOpsMixin.get_valid_mask_indices(m, padding_value=int(g[f"pad_{tag}"]))
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[f"idx_{tag}"])
+        assert kmax == int(g[f"kmax_{tag}"])
+        np.testing.assert_array_equal(n.cpu().numpy(), g[f"n_{tag}"])
+        assert idx.dtype == torch.int64
+
+
+def test_get_valid_mask_indices_random(ops):
+    from star_amd.nugget import NuggetOpsMixin
+    rng = np.random.default_rng(5)
+    for B, T in ((7, 1500), (3, 257), (1, 16), (4, 48)):
+        m = rng.random((B, T)) < 0.07
+        m[0, -1] = False
+        m[-1, -1] = True
+        m[B // 2, :] = False          # an empty row
+        o_idx, o_k, o_n = orc.valid_mask_indices(m, -1)
+        idx, kmax, n = NuggetOpsMixin.get_valid_mask_indices(dev(m))
+        assert kmax == o_k
+        np.testing.assert_array_equal(idx.cpu().numpy(), o_idx)
+        np.testing.assert_array_equal(n.cpu().numpy(), o_n)
+
+
+def test_fire_scan_forced_fire_only_inside_the_row(ops):
+    """lengths > T: every frame valid, no forced fire (the star_cif_fire_scan contract get_valid_mask_indices uses);
+    lengths == T: forced fire at T-1 as before."""
+    a = torch.full((2, 10), 0.26, device=DEV)          # integral: 1.04 at t = 3 (fire), 1.08 at t = 7 (fire), 0.60 at t = 9
+    idx, _, counts, _, _ = ops.cif_fire_scan(a, lengths=torch.tensor([10, 11], dtype=torch.int32, device=DEV))
+    c = counts.cpu().numpy()
+    i = idx.cpu().numpy()
+    assert list(i[0, :c[0]]) == [3, 7, 9] and list(i[1, :c[1]]) == [3, 7]     # the forced fire at 9 only in row 0
+
+
+# ------------------------------------------------------------------------------------------------ resize backward
+@pytest.mark.parametrize("name", ["resize_grad_plain", "resize_grad_fixup"])
+def test_resize_backward_golden(ops, name):
+    g = load(name)
+    a = dev(g["alphas"]).requires_grad_()
+    r = ops.cif_resize(a, dev(g["target_lengths"], torch.int32))
+    # forward as in round 1: fp64 row sums rounded once vs torch's fp32 sums
+    np.testing.assert_allclose(r.detach().cpu().numpy(), g["resized"], rtol=2e-5, atol=1e-7)
+    (r * dev(g["gout"])).sum().backward()
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g["dalphas"], rtol=1e-4, atol=1e-6)
+
+
+def test_resize_backward_random_and_mixin(ops):
+    """Random rows (some needing fix-ups) against the oracle's autograd; the mirrored NuggetOpsMixin.resize carries
+    the gradient (lm_cif_training trains the scorer through it, w2v_simul.py:558)."""
+    from star_amd.nugget import NuggetOpsMixin
+    gen = torch.Generator().manual_seed(3)
+    B, T = 9, 300
+    scores = torch.randn(B, T, generator=gen) - 1.0
+    scores[2, 17] = 9.0
+    scores[5, :] = -5.0
+    scores[5, 100] = 6.0
+    lengths = [300, 280, 40, 129, 64, 200, 7, 1, 300]
+    tgt = torch.tensor([30, 25, 9, 12, 6, 14, 3, 1, 2])
+    mask = torch.from_numpy(lmask(lengths, T))
+    alphas = torch.sigmoid(scores) * mask
+    gout = torch.randn(B, T, generator=gen)
+    ar = alphas.clone().requires_grad_()
+    r_ref = orc.resize(ar, tgt, differentiable=True)
+    (r_ref * gout).sum().backward()
+    ad = alphas.to(DEV).requires_grad_()
+    r = NuggetOpsMixin().resize(ad, tgt.to(DEV))
+    np.testing.assert_allclose(r.detach().cpu().numpy(), r_ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+    (r * gout.to(DEV)).sum().backward()
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), ar.grad.numpy(), rtol=2e-4, atol=2e-6)
+    assert (ad.grad.cpu().numpy() != 0).any()
+
+
+# ------------------------------------------------------------------------------------------------ attention dropout
+def _drop_case(B, h, L, K, hd, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, h, L, hd, generator=g)
+    k = torch.randn(B, h, K, hd, generator=g)
+    v = torch.randn(B, h, K, hd, generator=g)
+    sc = torch.randn(B, K, generator=g)
+    gout = torch.randn(B, h, L, hd, generator=g)
+    klen = [K] + [max(3, K - 37 * (i + 1)) for i in range(B - 1)]
+    return q, k, v, sc, gout, klen
+
+
+DROP_SHAPES = [(2, 8, 128, 375, 128, False, 0.1),      # configs[1]-shaped: fused backward
+               (2, 4, 24, 63, 96, False, 0.1),         # hd 96: general dQ / dK,dV kernels
+               (1, 8, 227, 229, 128, True, 0.1),       # configs[3]-shaped, ILK, L > 128: ring dQ + register dK/dV
+               (3, 2, 130, 200, 64, True, 0.25),
+               (26, 8, 128, 130, 64, True, 0.1),       # fused, hd 64, ILK
+               (2, 2, 60, 200, 64, False, 0.5)]
+
+
+@pytest.mark.parametrize("B,h,L,K,hd,ilk,p", DROP_SHAPES)
+def test_xattn_dropout_vs_oracle_same_mask(ops, B, h, L, K, hd, ilk, p):
+    """O, P (dropped + rescaled, as the reference returns it), dQ, dK, dV, dscores against the oracle fed the SAME keep
+    mask (restated from the specification in star_nugget.h); the kernel's mask equals that restatement bit for bit
+    (read off the zeros of p_out); every backward variant regenerates it."""
+    q, k, v, sc, gout, klen = _drop_case(B, h, L, K, hd, 1000 + L + K)
+    seed, offset = 0x1234_5678_9ABC_DEF1, 42 + L
+    keep, p_eff = orc.dropout_keep_mask(seed, offset, B, h, L, K, p)
+    n = keep.size
+    assert abs(keep.mean() - (1 - p_eff)) < 3 * (p_eff * (1 - p_eff) / n) ** 0.5 + 1e-9        # keep rate within 3 sigma
+    qr, kr, vr = (bf16_round(t).requires_grad_() for t in (q, k, v))
+    scr = sc.clone().requires_grad_()
+    kmask = torch.from_numpy(lmask(klen, K))
+    o_ref, p_ref = orc.xattn_core(qr, kr, vr, kmask, scr, ilk, drop_mask=torch.from_numpy(keep), drop_p=p_eff)
+    (o_ref * bf16_round(gout)).sum().backward()
+    key_len = torch.tensor(klen, dtype=torch.int32, device=DEV)
+    variants = [[]]
+    if hd in (64, 128):
+        variants += [[(ops.OVR_XA_BWD, 1)], [(ops.OVR_XA_DQ, 1), (ops.OVR_XA_DKV, 1)]]
+        if L <= 128:
+            variants += [[(ops.OVR_XA_BWD, 2)]]
+    try:
+        for switches in variants:
+            for w, val in switches:
+                ops.test_override(w, val)
+            qd, kd, vd = (t.to(torch.bfloat16).to(DEV).requires_grad_() for t in (q, k, v))
+            scd = sc.to(DEV).requires_grad_()
+            o, pw = ops.xattn(qd, kd, vd, bias=scd, key_len=key_len, ilk_diag=2 if ilk else -1, need_probs=True,
+                              dropout_p=p, dropout_rng=(seed, offset))
+            o.backward(gout.to(torch.bfloat16).to(DEV))
+            pk = pw.cpu().numpy()
+            seen = np.broadcast_to(kmask.numpy()[:, None, None, :], keep.shape).copy()
+            if ilk:
+                seen &= (np.arange(K)[None, :] <= np.arange(L)[:, None] + 2)[None, None]
+            # the kernel's zero pattern is exactly the oracle's mask (exp never underflows at these scales)
+            np.testing.assert_array_equal((pk != 0)[seen], keep[seen])
+            assert (pk[~seen] == 0).all()
+            close(pw, p_ref, "P", 2e-3)
+            close(o, o_ref, "O")
+            close(qd.grad, qr.grad, "dQ")
+            close(kd.grad, kr.grad, "dK")
+            close(vd.grad, vr.grad, "dV")
+            close(scd.grad, scr.grad, "dscores")
+            for w, _ in switches:
+                ops.test_override(w, 0)
+    finally:
+        for w in (ops.OVR_XA_BWD, ops.OVR_XA_DQ, ops.OVR_XA_DKV, ops.OVR_XA_NG):
+            ops.test_override(w, 0)
+
+
+def test_xattn_dropout_p0_is_bit_identical_and_state_advances(ops):
+    q, k, v, sc, gout, klen = _drop_case(3, 4, 64, 140, 128, 77)
+    qd, kd, vd = (t.to(torch.bfloat16).to(DEV) for t in (q, k, v))
+    scd = sc.to(DEV)
+    o0, _ = ops.xattn(qd, kd, vd, bias=scd)
+    o1, _ = ops.xattn(qd, kd, vd, bias=scd, dropout_p=0.0, dropout_rng=(1, 2))
+    assert torch.equal(o0, o1)
+    # per-device state: consecutive calls draw different masks, the backward regenerates the forward's mask
+    ops.reset_dropout_state(123)
+    qg = qd.clone().requires_grad_()
+    oa, pa = ops.xattn(qg, kd, vd, bias=scd, need_probs=True, dropout_p=0.3)
+    ob, pb = ops.xattn(qd, kd, vd, bias=scd, need_probs=True, dropout_p=0.3)
+    ka, kb = (pa != 0).cpu().numpy(), (pb != 0).cpu().numpy()
+    assert abs(ka.mean() - 0.7) < 0.01 and abs(kb.mean() - 0.7) < 0.01 and (ka != kb).mean() > 0.2
+    # gradient of the first call against the oracle with the mask read back from its p_out
+    qr = bf16_round(q).requires_grad_()
+    o_ref, _ = orc.xattn_core(qr, bf16_round(k), bf16_round(v), None, sc, False, drop_mask=torch.from_numpy(ka),
+                              drop_p=0.3)
+    (o_ref * bf16_round(gout)).sum().backward()
+    oa.backward(gout.to(torch.bfloat16).to(DEV))
+    close(oa, o_ref, "O")
+    close(qg.grad, qr.grad, "dQ")
+    # re-seeding reproduces the stream
+    ops.reset_dropout_state(123)
+    _, pc = ops.xattn(qd, kd, vd, bias=scd, need_probs=True, dropout_p=0.3)
+    assert torch.equal(pa, pc)
+
+
+def test_cross_attention_module_trains_with_default_attn_pdrop(ops):
+    """The reference's default GPT2Config has attn_pdrop = 0.1 (w2v_asr.py:134-145): the module accepts it, applies
+    dropout in training mode only, and gradients reach every projection."""
+    from star_amd.nugget import NuggetCrossAttention
+    torch.manual_seed(5)
+    d, h, B, L, K = 256, 4, 3, 20, 50
+    m = NuggetCrossAttention(d, h, attn_pdrop=0.1).to(DEV)
+    x = torch.randn(B, L, d, device=DEV)
+    mem = torch.randn(B, K, d, device=DEV)
+    sl = torch.randn(B, K, device=DEV, requires_grad=True)
+    m.eval()
+    with torch.no_grad():
+        e1 = m(x, encoder_hidden_states=mem, scorer_logits=sl)[0]
+        e2 = m(x, encoder_hidden_states=mem, scorer_logits=sl)[0]
+    assert torch.equal(e1, e2)
+    m.train()
+    t1, _, w = m(x, encoder_hidden_states=mem, scorer_logits=sl, output_attentions=True)
+    assert not torch.equal(t1, e1)
+    kept = (w != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.02
+    t1.square().mean().backward()
+    for name, prm in m.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all() and prm.grad.abs().sum() > 0, name
+    assert sl.grad is not None and sl.grad.abs().sum() > 0
+
+
+# ------------------------------------------------------------------------------------------------ a11: prefix bias
+@pytest.mark.parametrize("B,h,L,K,Kb,hd,ilk", [(2, 8, 128, 375, 200, 128, False), (3, 4, 40, 130, 1, 64, False),
+                                               (1, 8, 227, 229, 64, 128, True), (2, 2, 24, 63, 31, 96, False),
+                                               (26, 8, 100, 150, 77, 64, True)])
+def test_prefix_bias_shorter_than_keys(ops, B, h, L, K, Kb, hd, ilk):
+    """MyLlamaAttention's bias block (my_transformer.py:114-125): nugget logits cover only the first Kb < K keys and
+    are zero-extended.  The kernels take bias_len = Kb directly (no padded copy); d(bias) has Kb columns."""
+    from star_amd.nugget import score_biased_attn
+    q, k, v, _, gout, klen = _drop_case(B, h, L, K, hd, 9 + Kb)
+    sc = torch.randn(B, Kb, generator=torch.Generator().manual_seed(Kb))
+    qr, kr, vr = (bf16_round(t).requires_grad_() for t in (q, k, v))
+    scr = sc.clone().requires_grad_()
+    kmask = torch.from_numpy(lmask(klen, K))
+    o_ref, p_ref = orc.xattn_core(qr, kr, vr, kmask, scr, ilk)
+    (o_ref * bf16_round(gout)).sum().backward()
+    key_len = torch.tensor(klen, dtype=torch.int32, device=DEV)
+    for via_module_fn in (False, True):
+        qd, kd, vd = (t.to(torch.bfloat16).to(DEV).requires_grad_() for t in (q, k, v))
+        scd = sc.to(DEV).requires_grad_()
+        if via_module_fn:      # the drop-in _attn signature; key lengths stand in for the additive pad mask
+            o, pw = score_biased_attn(qd, kd, vd, None, None, scd, limit_cross_attn=ilk, key_lengths=key_len,
+                                      output_attentions=True)
+        else:
+            o, pw = ops.xattn(qd, kd, vd, bias=scd, key_len=key_len, ilk_diag=2 if ilk else -1, need_probs=True)
+        o.backward(gout.to(torch.bfloat16).to(DEV))
+        assert scd.grad.shape == (B, Kb)
+        close(pw, p_ref, "P", 2e-3)
+        close(o, o_ref, "O")
+        close(qd.grad, qr.grad, "dQ")
+        close(kd.grad, kr.grad, "dK")
+        close(vd.grad, vr.grad, "dV")
+        close(scd.grad, scr.grad, "dscores")
+
+
+# ------------------------------------------------------------------------------------------------ gather edge cases
+def test_gather_bf16_scores_and_out_of_range_clamp(ops):
+    """2-D bf16 scores (row_bytes = 2: the d = 1 score gather of w2v_simul.py:427 under bf16); an index outside
+    [-T, T) is clamped identically in forward and backward."""
+    T = 31
+    s = torch.randn(3, T).to(torch.bfloat16)
+    idx = torch.tensor([[0, 5, 30, -1], [3, -1, -1, -31], [1, 2, 2, 4]])
+    sd = s.to(DEV).requires_grad_()
+    out = ops.gather_rows(sd, idx.to(DEV))
+    assert torch.equal(out.detach().cpu(), s[torch.arange(3).unsqueeze(1), idx])
+    w = torch.randn(3, 4).to(torch.bfloat16)
+    out.backward(w.to(DEV))
+    acc = torch.zeros(3, T)
+    for b in range(3):
+        for j in range(4):
+            acc[b, idx[b, j].item()] += w[b, j].float()
+    assert torch.equal(sd.grad.cpu(), acc.to(torch.bfloat16))
+    # out of range: T + 5 -> frame T-1, -T - 3 -> frame 0, in both directions, for rows and for scalars
+    bad = torch.tensor([[T + 5, -T - 3, 7]])
+    for src in (torch.randn(1, T, 64), torch.randn(1, T)):
+        srcd = src.to(DEV).requires_grad_()
+        o = ops.gather_rows(srcd, bad.to(DEV))
+        ref = src[:, [T - 1, 0, 7]]
+        assert torch.equal(o.detach().cpu(), ref)
+        o.backward(torch.ones_like(o))
+        gsum = srcd.grad.cpu().reshape(T, -1)[:, 0]
+        assert gsum[T - 1] == 1 and gsum[0] == 1 and gsum[7] == 1 and gsum.sum() == 3
+    with pytest.raises(TypeError):
+        ops.gather_rows(torch.zeros(1, 4, 8, dtype=torch.float16, device=DEV), bad.to(DEV))
+
+
+# ------------------------------------------------------------------------------------------------ scorer hint
+def test_scorer_hint_does_not_leak_into_later_backward(ops):
+    """after a step that used the sparse-row hint, a dense loss through the same scorer must get the
+    full gradient (the hint is single-use), and a hint set after a SECOND forward only binds to that forward."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(0)
+    d, N = 256, 260
+    sc = NuggetScorer(d).to(DEV)
+    x = torch.randn(2, N // 2, d, device=DEV).to(torch.bfloat16)
+    gs = torch.randn(2, N // 2, device=DEV)
+
+    def grads(set_rows):
+        sc.zero_grad()
+        s = sc(x).squeeze(-1)
+        if set_rows is not None:
+            sc.set_active_rows(set_rows)
+        (s * gs).sum().backward()
+        return [p.grad.clone() for p in sc.parameters()]
+
+    dense = grads(None)
+    rows = torch.arange(0, N, 5, dtype=torch.int32, device=DEV)
+    sparse = grads(rows)
+    assert not torch.equal(sparse[0], dense[0])            # only the listed rows contributed
+    again = grads(None)                                    # the next step forgets the hint: dense, not stale
+    for a, b in zip(again, dense):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        grads(torch.arange(N + 1, dtype=torch.int32, device=DEV))

@@ -39,9 +39,36 @@ def test_cross_attention_parameter_names_and_conv1d_layout():
         NuggetCrossAttention(50, 4)                                # embed_dim must be divisible by num_heads
     with pytest.raises(ValueError):
         m(torch.zeros(1, 2, d))                                    # cross-attention needs encoder_hidden_states
+    # the reference's default decoder config (attn_pdrop 0.1, w2v_asr.py:134-145) is accepted: dropout runs inside the
+    # kernels in training mode, so on CPU tensors the call reaches the "no CPU fallback" error, not a refusal
     drop = NuggetCrossAttention(d, 4, attn_pdrop=0.1)
-    with pytest.raises(NotImplementedError):                       # refused loudly in training, fine in eval
+    assert drop.attn_pdrop == pytest.approx(0.1) and drop.training
+    with pytest.raises(star_amd.ops.StarDeviceError):
         drop(torch.zeros(1, 2, d), encoder_hidden_states=torch.zeros(1, 3, d))
+    with pytest.raises(ValueError):
+        NuggetCrossAttention(d, 4, attn_pdrop=1.0)
+
+
+def test_active_rows_hint_is_single_use():
+    """the active-row hint must not leak into a later forward/backward of the same scorer."""
+    h = star_amd.ops.ActiveRows()
+    rows = torch.arange(4, dtype=torch.int32)
+    f1 = h._begin_forward()
+    h.set(rows)                              # after the forward (what nugget_step_asr does): bound to f1
+    f2 = h._begin_forward()                  # e.g. a second forward for a dense regulariser
+    assert h._take(f2) is None               # ... runs dense
+    assert h._take(f1) is rows               # the owner consumes it
+    assert h._take(f1) is None and h.rows is None
+    h.set(rows)                              # a second backward through the same forward (retain_graph): set again
+    assert h._take(f1) is None and h._take(f2) is rows
+    f3 = h._begin_forward()                  # the next step forgets to set it: dense
+    assert h._take(f3) is None
+    h.set(rows)
+    h.set(None)
+    assert h._take(f3) is None
+    fresh = star_amd.ops.ActiveRows()
+    fresh.set(rows)                          # before any forward: bound to the next one
+    assert fresh._take(fresh._begin_forward()) is rows
 
 
 def test_error_behaviour_without_a_gpu():

@@ -117,7 +117,9 @@ def test_xattn(name):
     g = load(name)
     q, k, v, sc = (torch.from_numpy(g[n]).requires_grad_() for n in ("q", "k", "v", "scores"))
     kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
-    o, p = orc.xattn_core(q, k, v, kmask, sc, bool(g["ilk"]))
+    # xattn_drop_*: attention-probability dropout (my_transformer.py:595) with the reference's mask given
+    drop = dict(drop_mask=torch.from_numpy(g["keep"]), drop_p=float(g["drop_p"])) if "keep" in g else {}
+    o, p = orc.xattn_core(q, k, v, kmask, sc, bool(g["ilk"]), **drop)
     (o * torch.from_numpy(g["gout"])).sum().backward()
     tol = dict(rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o.detach().numpy(), g["o"], **tol)
@@ -253,3 +255,46 @@ def test_type_embed_golden(name):
     (out * torch.from_numpy(g["gout"])).sum().backward()
     np.testing.assert_array_equal(x.grad.numpy(), g["dx"])
     np.testing.assert_allclose(emb.grad.numpy(), g["demb"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ round 2: resize gradient, valid indices, dropout mask
+@pytest.mark.parametrize("name", ["resize_grad_plain", "resize_grad_fixup"])
+def test_resize_gradient_golden(name):
+    """resize differentiated as lm_cif_training does (w2v_simul.py:558): oracle autograd == reference autograd."""
+    g = load(name)
+    a = torch.from_numpy(g["alphas"]).clone().requires_grad_()
+    r = orc.resize(a, torch.from_numpy(g["target_lengths"]), differentiable=True)
+    np.testing.assert_array_equal(r.detach().numpy(), g["resized"])
+    (r * torch.from_numpy(g["gout"])).sum().backward()
+    np.testing.assert_allclose(a.grad.numpy(), g["dalphas"], rtol=1e-5, atol=1e-6)
+    if name.endswith("fixup"):
+        assert (g["resized"] != (g["alphas"] * (g["target_lengths"] / g["alphas"].sum(1))[:, None]).astype(np.float32)).any()
+
+
+def test_valid_mask_indices_golden():
+    g = load("valid_indices")
+    for tag in "abcd":
+        idx, kmax, n = orc.valid_mask_indices(g[f"mask_{tag}"], int(g[f"pad_{tag}"]))
+        np.testing.assert_array_equal(idx, g[f"idx_{tag}"])
+        assert kmax == int(g[f"kmax_{tag}"])
+        np.testing.assert_array_equal(n, g[f"n_{tag}"])
+
+
+def test_dropout_keep_mask_statistics():
+    """The kernel's counter-based mask (restated from star_nugget.h): keep rate within 3 sigma of 1 - p_eff, streams
+    of different (b, h), seeds and offsets differ, and the same arguments give the same mask."""
+    p = 0.1
+    m, p_eff = orc.dropout_keep_mask(1234, 7, 3, 4, 64, 200, p)
+    assert abs(p_eff - p) < 1e-6
+    n = m.size
+    assert abs(m.mean() - (1 - p_eff)) < 3 * (p_eff * (1 - p_eff) / n) ** 0.5
+    per = m.reshape(12, -1)
+    sig = (p_eff * (1 - p_eff) / per.shape[1]) ** 0.5
+    assert (np.abs(per.mean(1) - (1 - p_eff)) < 4.5 * sig).all()
+    assert all((per[i] != per[j]).mean() > 0.1 for i in range(12) for j in range(i))
+    m2, _ = orc.dropout_keep_mask(1234, 8, 3, 4, 64, 200, p)
+    m3, _ = orc.dropout_keep_mask(1235, 7, 3, 4, 64, 200, p)
+    assert (m != m2).mean() > 0.1 and (m != m3).mean() > 0.1
+    m4, _ = orc.dropout_keep_mask(1234, 7, 3, 4, 64, 200, p)
+    assert np.array_equal(m, m4)
+    assert orc.dropout_keep_mask(1, 2, 1, 1, 4, 4, 0.0)[0].all()

@@ -63,11 +63,13 @@ for w in a.what:
         else:
             s = sc(x).squeeze(-1)
             rows = torch.stack([torch.randperm(T, device=dev)[:K] + b * T for b in range(B)]).reshape(-1).int()
-            sc.set_active_rows(rows)
             gs = torch.zeros_like(s); gs.view(-1)[rows.long()] = 1.0
             R = rows.numel()
-            timeit("scorer_bwd (+dX)", lambda: torch.autograd.grad(s, (x, *sc.parameters()), gs, retain_graph=True),
-                   flops=R * 6.0 * d * d)
+
+            def bwd():
+                sc.set_active_rows(rows)          # single-use hint
+                return torch.autograd.grad(s, (x, *sc.parameters()), gs, retain_graph=True)
+            timeit("scorer_bwd (+dX)", bwd, flops=R * 6.0 * d * d)
     elif w == "select":
         s = torch.randn(B, T, device=dev)
         ln = torch.full((B,), T, dtype=torch.int32, device=dev)
