@@ -10,7 +10,7 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host
  *     synchronisation and no readback, and is re-entrant and thread-safe: the only process-wide state is
  *     a set of idempotent "kernel attribute set on device n" bits (atomics) and the test-only switches of
- *     star_test_override();
+ *     star_test_override(); the one documented exception is star_scorer_fwd_static (its scratch array);
  *   - return value: 0 on success, a negative STAR_ERR_* otherwise; star_last_error() then returns a
  *     thread-local message.  Nothing throws across the ABI;
  *   - tensors are dense row-major unless strides are given (strides are in ELEMENTS);
@@ -196,6 +196,18 @@ size_t star_scorer_fwd_workspace(int64_t N, int d);
 int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2,
                     const float* b2, int64_t N, int d, float* scores, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* star_scorer_fwd without a workspace argument and without any allocation.  NO counterpart in the reference: it is
+ * for callers that cannot allocate device memory around the call (code under HIP-graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  The partial scores go to a file-scope __device__ array of
+ * STAR_SCORER_STATIC_SCRATCH_BYTES inside the library (one copy per GPU, looked up once per device with
+ * hipGetSymbolAddress at the first call on that device -- make that first call outside a stream capture).
+ * Limit: star_scorer_fwd_workspace(N, d) <= STAR_SCORER_STATIC_SCRATCH_BYTES, i.e. N <= 262,144 frames at d = 1024;
+ * larger inputs return STAR_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array: calls that overlap in time
+ * on one GPU (two streams, two threads) race -- serialise them or use star_scorer_fwd.  Same kernels and the same
+ * bits as star_scorer_fwd. */
+#define STAR_SCORER_STATIC_SCRATCH_BYTES (4u << 20)
+int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                           int64_t N, int d, float* scores, void* stream);
 /* Backward for the R rows listed in rows[] (frame ids into x; the frames whose dscore is non-zero):
  *   dscores [N] fp32 (full), rows [R] int32, w1t = transpose of w1 ([in,out] bf16) for dx.
  * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),

@@ -726,6 +726,38 @@ static inline int bwd_splits(int d) {
 
 }  // namespace star
 
+// ---- scratch of star_scorer_fwd_static: the per-column-tile partial scores live in this array instead of a
+// caller workspace.  One copy per GPU the library runs on, held until the process ends.  The name is a host-side
+// stand-in, not a device address: host code only ever uses the per-device pointer from hipGetSymbolAddress.
+namespace star {
+constexpr size_t STATIC_SCRATCH_BYTES = STAR_SCORER_STATIC_SCRATCH_BYTES;
+}
+static __device__ __align__(256) unsigned char scratch[star::STATIC_SCRATCH_BYTES];
+namespace star {
+static std::atomic<void*> g_scratch_ptr[64];
+// device address of `scratch` on the CURRENT device (looked up once per device, with that device current)
+static void* static_scratch(int* rc) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("star_scorer_fwd_static: cannot identify the current device");
+        *rc = STAR_ERR_LAUNCH;
+        return nullptr;
+    }
+    void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            set_error("star_scorer_fwd_static: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+            *rc = STAR_ERR_LAUNCH;
+            return nullptr;
+        }
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    *rc = STAR_OK;
+    return ptr;
+}
+}  // namespace star
+
 extern "C" size_t star_scorer_fwd_workspace(int64_t N, int d) {
     using namespace star;
     if (N <= 0 || d <= 0) return 0;
@@ -762,6 +794,23 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
                        p.partial_ld, (d + BN - 1) / BN, b2, N, scores);
     STAR_LAUNCH_CHECK("star_scorer_fwd");
     return STAR_OK;
+}
+
+extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2,
+                                      const float* b2, int64_t N, int d, float* scores, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(N >= 1 && d >= 128 && d % 128 == 0, "star_scorer_fwd_static: bad shape N=%lld d=%d", (long long)N, d);
+    const size_t need = star_scorer_fwd_workspace(N, d);
+    if (need > STATIC_SCRATCH_BYTES) {
+        set_error("star_scorer_fwd_static: N=%lld x d=%d needs %zu bytes of scratch, the static array holds %zu "
+                  "(use star_scorer_fwd with a caller workspace)", (long long)N, d, need, (size_t)STATIC_SCRATCH_BYTES);
+        return STAR_ERR_WORKSPACE;
+    }
+    int rc = STAR_OK;
+    void* ptr = static_scratch(&rc);
+    if (!ptr) return rc;
+    // every partial the finish kernel reads is written by the GEMM of THIS call: nothing has to start at zero
+    return star_scorer_fwd(x, w1, b1, w2, b2, N, d, scores, ptr, STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
