@@ -210,11 +210,13 @@ def main():
         wsb = _lib.lib().star_scorer_fwd_workspace(N, d)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         sc = torch.empty(N, dtype=torch.float32, device=dev)
+        # the training forward: it also emits the ReLU sign bits the backward consumes
+        bits = torch.empty(_lib.lib().star_scorer_relu_bits_bytes(N, d), dtype=torch.uint8, device=dev)
 
         def launch():
             _lib.check(_lib.lib().star_scorer_fwd(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
-                                                  b2f.data_ptr(), N, d, sc.data_ptr(), ws.data_ptr(), wsb,
-                                                  _lib.stream_ptr()), "star_scorer_fwd")
+                                                  b2f.data_ptr(), N, d, sc.data_ptr(), bits.data_ptr(), ws.data_ptr(),
+                                                  wsb, _lib.stream_ptr()), "star_scorer_fwd")
         for _ in range(3):
             launch()
         iters = max(args.steps, 10)

@@ -44,8 +44,9 @@ const char* star_last_error(void);
 #define STAR_OVR_XA_BWD 0  /* attention backward: 1 = split dQ + dK/dV kernels, 2 = the fused kernel whenever legal */
 #define STAR_OVR_XA_DQ 1   /* 1 = the general (register-staged) dQ kernel */
 #define STAR_OVR_XA_DKV 2  /* 1 = the general dK/dV kernel */
-#define STAR_OVR_XA_NG 3   /* key groups of the attention forward / general dQ: 1 or 2 */
-#define STAR_OVR_COUNT 4
+#define STAR_OVR_XA_NG 3   /* key groups of the register-staged attention forward / general dQ: 1 or 2 */
+#define STAR_OVR_XA_FWD 4  /* attention forward: 1 = the register-staged kernel instead of the LDS-DMA ring */
+#define STAR_OVR_COUNT 5
 int star_test_override(int which, int value);
 
 /* ---------------------------------------------------------------- a2 + a3: top-k anchor select
@@ -190,11 +191,16 @@ int star_type_embed_grad(const void* dout, const int64_t* table, int dtype, int6
  * (w2v_asr.py:113-117,553; w2v_simul.py:144-148,410-411).
  *   x   [N,d] bf16 frames (N = B*T)       w1 [d,d] bf16 in nn.Linear layout [out,in]
  *   b1  [d] fp32   w2 [d] fp32   b2 [1] fp32 (device)      scores [N] fp32
- * d must be a multiple of 128.  The hidden activation H is never written to memory.
+ * d must be a multiple of 128.  The hidden activation H is never written to memory; what the backward needs of it,
+ * the ReLU sign bits (1 bit per element: 6 MB at N = 48,000, d = 1024), goes to relu_bits when that is non-NULL:
+ *   relu_bits  star_scorer_relu_bits_bytes(N,d) bytes, 16-byte aligned, opaque to the caller (the sign bits in the
+ *              forward GEMM's accumulator order: one 8-KiB blob per 256 x 256 output tile); only star_scorer_bwd
+ *              reads it.  NULL (inference) skips it.
  * workspace: star_scorer_fwd_workspace(N,d) bytes (per-column-tile partial scores). */
 size_t star_scorer_fwd_workspace(int64_t N, int d);
+size_t star_scorer_relu_bits_bytes(int64_t N, int d);
 int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2,
-                    const float* b2, int64_t N, int d, float* scores, void* workspace,
+                    const float* b2, int64_t N, int d, float* scores, void* relu_bits, void* workspace,
                     size_t workspace_bytes, void* stream);
 /* star_scorer_fwd without a workspace argument and without any allocation.  NO counterpart in the reference: it is
  * for callers that cannot allocate device memory around the call (code under HIP-graph capture, tight serving
@@ -207,9 +213,13 @@ int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float*
  * bits as star_scorer_fwd. */
 #define STAR_SCORER_STATIC_SCRATCH_BYTES (4u << 20)
 int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
-                           int64_t N, int d, float* scores, void* stream);
-/* Backward for the R rows listed in rows[] (frame ids into x; the frames whose dscore is non-zero):
- *   dscores [N] fp32 (full), rows [R] int32, w1t = transpose of w1 ([in,out] bf16) for dx.
+                           int64_t N, int d, float* scores, void* relu_bits, void* stream);
+/* Backward for the R rows listed in rows[] (frame ids into x; the frames whose dscore is non-zero; no duplicates).
+ * There is no recompute of H: with G' = ds * relu'(H) (from relu_bits) and U = G'^T X_sel,
+ *   dW1 = diag(w2) U,  db1 = w2 * colsum(G'),  dw2[n] = <W1[n], U[n]> + b1[n] colsum(G')[n],  dX = G' (diag(w2) W1).
+ *   dscores [N] fp32 (full), rows [R] int32, relu_bits as written by star_scorer_fwd for the same x / w1 / b1,
+ *   w1 [d,d] bf16 ([out,in], as in the forward), w1ts = bf16 of (diag(w2) W1)^T ([in,out]; star_cast_transpose_bf16
+ *   with t_scale = w2 writes it), needed only for dx.
  * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),
  *   dx [N,d] bf16 or NULL: rows listed in rows[] are written; all other rows are zero-filled by the call
  *   unless dx_zeroed != 0 says the caller has done so already.
@@ -222,13 +232,15 @@ int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const
  *   may overlap in time (other threads, other stream pairs) bring their own sets, so the library holds no event.
  * workspace: star_scorer_bwd_workspace(R,d) bytes. */
 size_t star_scorer_bwd_workspace(int64_t R, int d);
-int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1,
-                    const float* w2, const float* dscores, const int32_t* rows, int64_t R,
+int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, const float* b1,
+                    const float* w2, const void* relu_bits, const float* dscores, const int32_t* rows, int64_t R,
                     int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
                     int dx_zeroed, void* workspace, size_t workspace_bytes, void* stream,
                     void* aux_stream, void* const* aux_events_host);
-/* fp32 [rows,cols] -> bf16 copy and bf16 transpose (the per-step weight cast of W1). */
-int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream);
+/* fp32 [rows,cols] -> bf16 copy (dst, may be NULL) and bf16 transpose (dst_t, may be NULL): the per-step weight cast
+ * of W1.  t_scale [rows] fp32 or NULL: dst_t[c][r] = bf16(src[r][c] * t_scale[r]) (dst is never scaled). */
+int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, const float* t_scale,
+                             void* stream);
 
 /* ---------------------------------------------------------------- a8 (+a11): score-biased attention core
  * Replaces MyGPT2Attention._attn for cross-attention (src/models/my_transformer.py:535-603):

@@ -8,10 +8,10 @@
 //
 // One "NT" GEMM template (C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous) serves forward
 // and backward through its epilogue:
-//   EPI_SCORE   relu/bias/w2 row-dot  -> per-column-tile partial scores      (forward)
-//   EPI_DH      G = ds[m]*w2[n]*(H>0) -> G, G^T (bf16) + column partials for dw2/db1   (backward 1)
-//   EPI_SLAB    fp32 split-K slab store                                      (dW1 = G^T X)
-//   EPI_ROWS    bf16 store with row scatter                                  (dX = G W1)
+//   EPI_SCORE   relu/bias/w2 row-dot  -> per-column-tile partial scores (+ the ReLU sign bits, 1 bit per element of H,
+//               which are all the backward needs of H: there is no recompute GEMM)               (forward)
+//   EPI_SLAB    fp32 split-K slab store                                      (U = G'^T X_sel, G' = ds * relu'(H))
+//   EPI_ROWS    bf16 store with row scatter                                  (dX = G' (diag(w2) W1))
 // Tile 256x256x64, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
 // registers).  Operands are staged with global_load_lds (16 B/lane, LDS image lane-linear) into two LDS buffers
 // of four 16-KiB half-tiles each (128 KiB).  A K tile is consumed in four phases, one accumulator quadrant
@@ -43,7 +43,7 @@ constexpr int SCORE_LDS = GEMM_LDS + 4096 + 2 * SCORE_BW_MAXN * 4;   // + row-re
 // accumulator quadrant row h (tile rows wr*128 + h*64 ..); B-half h the 32 columns wc*64 + h*32 .. of all four
 // wave columns.
 enum { H_B0 = 0, H_A0 = 1, H_B1 = 2, H_A1 = 3 };
-// epilogue staging (EPI_DH, EPI_ROWS): every wave parks its 128 x 64 bf16 output tile TRANSPOSED in LDS
+// epilogue staging (EPI_ROWS): every wave parks its 128 x 64 bf16 output tile TRANSPOSED in LDS
 // ([64 n][128 m], pitch 272 B) so that global stores are 16 B per lane along whichever axis the consumer wants
 constexpr int EP_PITCH = 128 * 2 + 16;
 constexpr int EP_WAVE_BYTES = 64 * EP_PITCH;      // 17 KiB
@@ -51,7 +51,7 @@ constexpr int EP_RED_OFF = NWAVE * EP_WAVE_BYTES; // reduction scratch behind th
 constexpr int EPI_LDS = EP_RED_OFF + 8192;        // 144 KiB
 static_assert(EPI_LDS >= GEMM_LDS && EPI_LDS <= 160 * 1024, "epilogue staging must cover the ring and fit the CU");
 
-enum { EPI_SCORE = 0, EPI_DH = 1, EPI_SLAB = 2, EPI_ROWS = 3 };
+enum { EPI_SCORE = 0, EPI_SLAB = 2, EPI_ROWS = 3 };
 
 struct GemmParams {
     const __bf16* A;
@@ -65,13 +65,9 @@ struct GemmParams {
     // epilogue operands
     const float* b1;
     const float* w2;
-    const float* ds;          // dscores, indexed by a_rows[m] (EPI_DH)
     float* partial;           // EPI_SCORE: [nbn][Mpad]
     int64_t partial_ld;
-    __bf16* G;                // EPI_DH: [Mpad][N]
-    __bf16* GT;               // EPI_DH: [N][Mpad]
-    int64_t ldgt;
-    float* colpart;           // EPI_DH: [2][nbm][N]  (0: dw2, 1: db1), then [nbm] partial sums of ds (db2)
+    uint32_t* relu_bits;      // EPI_SCORE (optional): sign bits of H in accumulator order (relu_bit_addr below)
     float* slab;              // EPI_SLAB: [splits][M][N]
     __bf16* out;              // EPI_ROWS: out[out_rows[m]][n]
     int64_t ldo;
@@ -197,12 +193,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     make_src(src, m0, n0);
 
     f32x4 acc[TM][TN];
-
-    // EPI_DH: the dscores of this tile's 256 rows are fetched by one thread per row while the main loop runs
-    float my_ds = 0.f;
-    if constexpr (EPI == EPI_DH) {
-        if (tid < BM && m0 + tid < p.a_rows_n) my_ds = p.ds[p.a_rows[m0 + tid]];
-    }
 
     // stage half-tile KIND of K tile TT of the current output tile; K tiles past the end belong to the next
     // output tile of this workgroup (persistent mode).  UB = number of K tiles consumed so far: buffer parity.
@@ -361,13 +351,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                 ww[tn] = n < p.N ? p.w2[n] : 0.f;
             }
         }
+        // ReLU sign bits (all the backward needs of H) are packed per lane while the row dot is formed: element
+        // e = (tm*4 + tn)*4 + j goes to bit 31 - e%32 of the lane's dword e/32 (v_alignbit shifts in the sign of -h)
+        uint32_t hb[TM / 2] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
+            float srow[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float h = acc[tm][tn][j] + bb[tn];
+                    srow[j] += fmaxf(h, 0.f) * ww[tn];
+                    hb[tm >> 1] = __builtin_amdgcn_alignbit(hb[tm >> 1], __float_as_uint(0.f - h), 31);
+                }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) s += fmaxf(acc[tm][tn][j] + bb[tn], 0.f) * ww[tn];
+                float s = srow[j];
                 // sum over the 16 lanes that share this row
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
@@ -375,6 +375,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                 s += __shfl_xor(s, 8, 64);
                 if (ccol == 0) red[(wrow0 + tm * 16 + crow4 + j) * 4 + wc] = s;
             }
+        }
+        if (p.relu_bits) {
+            // tile blob: [wave 8][plane 4][lane 64] dwords -> every store instruction writes 256 contiguous bytes
+            uint32_t* dst = p.relu_bits + ((int64_t)(m_tile * nbn + n_tile) * NWAVE + wid) * (TM / 2) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < TM / 2; ++q) dst[q * 64] = hb[q];
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's partial sums are in LDS
         __builtin_amdgcn_s_barrier();
@@ -385,84 +391,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
         }
         // (the next write to `red` is a whole K loop of barriers away)
-    } else if constexpr (EPI == EPI_DH) {
-        uint8_t* W = lds + wid * EP_WAVE_BYTES;
-        float* red2 = (float*)(lds + EP_RED_OFF);
-        float* dsl = red2 + 1280;                    // [256] dscores of the tile rows
-        if (tid < BM) dsl[tid] = my_ds;
-        __syncthreads();
-        float bb[TN], ww[TN], c_dw2[TN], c_db1[TN];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wcol0 + tn * 16 + ccol;
-            bb[tn] = n < p.N ? p.b1[n] : 0.f;
-            ww[tn] = n < p.N ? p.w2[n] : 0.f;
-            c_dw2[tn] = 0.f;
-            c_db1[tn] = 0.f;
-        }
-        float ds_sum = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const f32x4 dsv = *(const f32x4*)(dsl + wrow0 + tm * 16 + crow4);
-            ds_sum += (dsv[0] + dsv[1]) + (dsv[2] + dsv[3]);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                bf16x4 gt;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float h = acc[tm][tn][j] + bb[tn];
-                    const float g = (h > 0.f) ? dsv[j] * ww[tn] : 0.f;
-                    c_dw2[tn] += dsv[j] * fmaxf(h, 0.f);
-                    c_db1[tn] += g;
-                    gt[j] = (__bf16)g;
-                }
-                *(bf16x4*)(W + (tn * 16 + ccol) * EP_PITCH + (tm * 16 + crow4) * 2) = gt;
-            }
-            // pin the running column sums here: without this the instruction scheduler sinks the whole chain of
-            // adds to the end of the epilogue and keeps (spills) every g and h value until then
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(c_dw2[tn]), "+v"(c_db1[tn]));
-        }
-        // the tile is wave-private: LDS operations of one wave complete in order, no workgroup barrier needed
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        ep_store_nrows(W, p.GT, p.ldgt, n0 + wcol0, m0 + wrow0, p.N, lane);
-        if (p.G && n0 + wcol0 < p.N) {      // G (row-major) only feeds the dX GEMM: skipped when dX is not wanted
-            __bf16* gdst = p.G + (int64_t)(m0 + wrow0 + (lane & 15)) * p.N + n0 + wcol0 + 8 * (lane >> 4);
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) *(u32x4*)(gdst + nh * 32) = ep_read_mrow(W, mb, nh, lane);
-                gdst += (int64_t)16 * p.N;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // column sums over this wave's 128 rows: lanes with equal (lane & 15) hold the same column
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            c_dw2[tn] += __shfl_xor(c_dw2[tn], 16, 64);
-            c_dw2[tn] += __shfl_xor(c_dw2[tn], 32, 64);
-            c_db1[tn] += __shfl_xor(c_db1[tn], 16, 64);
-            c_db1[tn] += __shfl_xor(c_db1[tn], 32, 64);
-            if (lane < 16) {
-                const int c = wcol0 + tn * 16 + ccol;
-                red2[(c * 2 + wr) * 2 + 0] = c_dw2[tn];
-                red2[(c * 2 + wr) * 2 + 1] = c_db1[tn];
-            }
-        }
-        // db2 partial: sum of ds over this tile's 256 rows (lanes 0,16,32,48 hold distinct rows)
-        ds_sum += __shfl_xor(ds_sum, 16, 64);
-        ds_sum += __shfl_xor(ds_sum, 32, 64);
-        if (lane == 0 && wc == 0) red2[1024 + wr] = ds_sum;
-        __syncthreads();
-        if (tid == 0 && n_tile == 0) p.colpart[(int64_t)2 * nbm * p.N + m_tile] = red2[1024] + red2[1025];
-        if (tid < BN && n0 + tid < p.N) {
-            const int64_t o = (int64_t)m_tile * p.N + n0 + tid;
-            const float* rc = red2 + tid * 4;
-            p.colpart[o] = rc[0] + rc[2];
-            p.colpart[(int64_t)nbm * p.N + o] = rc[1] + rc[3];
-        }
     } else if constexpr (EPI == EPI_SLAB) {
         float* slab = p.slab + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -570,15 +498,17 @@ __global__ __launch_bounds__(256) void gather_transpose_kernel(const __bf16* __r
 
 // dst[r][c] = bf16(src[r][c]);  dst_t[c][r] = bf16(src[r][c])
 __global__ __launch_bounds__(256) void cast_transpose_generic_kernel(const float* __restrict__ src, int rows, int cols,
-                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t) {
+                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t,
+                                                             const float* __restrict__ t_scale) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int rr = ty; rr < 64; rr += 4) {
         const int r = r0 + rr, c = c0 + tx;
         float v = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
-        tile[rr][tx] = v;
         if (dst && r < rows && c < cols) dst[(int64_t)r * cols + c] = (__bf16)v;
+        if (t_scale && r < rows) v *= t_scale[r];
+        tile[rr][tx] = v;
     }
     __syncthreads();
     if (dst_t)
@@ -590,7 +520,8 @@ __global__ __launch_bounds__(256) void cast_transpose_generic_kernel(const float
 
 // same for rows % 64 == 0 and cols % 64 == 0: 16-byte accesses on every side
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, int rows, int cols,
-                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t) {
+                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dst_t,
+                                                             const float* __restrict__ t_scale) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TP_PITCH];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int t = threadIdx.x, c = t & 7;
@@ -599,79 +530,173 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         const int rr = (t >> 3) + pass * 32;
         const float* sp = src + (int64_t)(r0 + rr) * cols + c0 + c * 8;
         const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
-        bf16x8 v;
+        const float sc = t_scale ? t_scale[r0 + rr] : 1.f;
+        bf16x8 v, vs;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[k] = (__bf16)a[k];
             v[4 + k] = (__bf16)b[k];
+            vs[k] = (__bf16)(a[k] * sc);
+            vs[4 + k] = (__bf16)(b[k] * sc);
         }
         if (dst) *(bf16x8*)(dst + (int64_t)(r0 + rr) * cols + c0 + c * 8) = v;
-        *(bf16x8*)(tile + rr * TP_PITCH + c * 16) = v;
+        *(bf16x8*)(tile + rr * TP_PITCH + c * 16) = vs;
     }
     __syncthreads();
     if (dst_t) tp_write_out(tile, dst_t, rows, c0, r0);
 }
 
-// dw1 = sum of split-K slabs; db1/dw2 = sum of column partials; db2 = sum of dscores over rows[]
-__global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __restrict__ slab, int splits,
-                                                                int64_t dd, float* __restrict__ dw1,
-                                                                const float* __restrict__ colpart, int nbm, int d,
-                                                                float* __restrict__ dw2, float* __restrict__ db1,
-                                                                float* __restrict__ db2, int nblk_dw1) {
-    if ((int)blockIdx.x < nblk_dw1) {
-        // dw1: sum of the split-K slabs, 4 floats per thread
-        const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-        if (i < dd) {
-            // four slabs per round: their loads are independent and in flight together (a rolled loop waits for
-            // every slab in turn); the summation order stays fixed
-            f32x4 s = *(const f32x4*)(slab + i);
-            int k = 1;
-            for (; k + 3 < splits; k += 4) {
-                const f32x4 v0 = *(const f32x4*)(slab + (int64_t)(k + 0) * dd + i);
-                const f32x4 v1 = *(const f32x4*)(slab + (int64_t)(k + 1) * dd + i);
-                const f32x4 v2 = *(const f32x4*)(slab + (int64_t)(k + 2) * dd + i);
-                const f32x4 v3 = *(const f32x4*)(slab + (int64_t)(k + 3) * dd + i);
-                s += v0;
-                s += v1;
-                s += v2;
-                s += v3;
-            }
-            for (; k < splits; ++k) s += *(const f32x4*)(slab + (int64_t)k * dd + i);
-            *(f32x4*)(dw1 + i) = s;
-        }
-        return;
+// Where the forward parks the sign bit of H[m][n] (accumulator order of the 256 x 256 tile, see the EPI_SCORE
+// epilogue): dword index and bit position.  Row m: wr = (m>>7)&1, tm = (m>>4)&7, g = (m>>2)&3, j = m&3; column n:
+// wc = (n>>6)&3, tn = (n>>4)&3, c = n&15.  The 16 dwords of (row, wave column) are contiguous (one per c).
+__host__ __device__ static inline int64_t relu_bit_dword(int64_t m, int n, int nbn) {
+    const int64_t tile = (m >> 8) * nbn + (n >> 8);
+    const int wave = (int)((m >> 7) & 1) * 4 + ((n >> 6) & 3);
+    const int plane = (int)((m >> 5) & 3), lane = (int)((m >> 2) & 3) * 16 + (n & 15);
+    return ((tile * NWAVE + wave) * (TM / 2) + plane) * 64 + lane;
+}
+__host__ __device__ static inline int relu_bit_pos(int64_t m, int n) {
+    return 31 - ((int)((m >> 4) & 1) * 16 + ((n >> 4) & 3) * 4 + (int)(m & 3));
+}
+
+// G' = ds * relu'(H) for the R listed rows, from the forward's sign bits: G' row-major (the dX GEMM's A operand, only
+// when dX is wanted), G'^T (the dW1 GEMM's A operand), and per 64-row block the column sums c[n] = sum_r G'[r][n]
+// (fp32 ds, not the bf16 copy) and sum_r ds[r].  One workgroup = 64 rows x 128 columns (two wave columns of the
+// forward's tile: 2 x 64 B of bits per row, staged in LDS with the row's dscore).  Memory bound: 2 * Rpad * d * 2
+// bytes written, R * d / 8 * 8 read (a row's bits share their 64-byte lines with 7 other rows).
+constexpr int GB_ROWS = 64, GB_COLS = 128, GB_PITCH = 33;      // LDS dwords per row (32 + 1: bank spread)
+__global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __restrict__ bits, int nbn,
+                                                           const float* __restrict__ ds, const int32_t* __restrict__ rows,
+                                                           int R, int Rpad, int d, __bf16* __restrict__ G,
+                                                           __bf16* __restrict__ GT, float* __restrict__ colpart,
+                                                           float* __restrict__ dspart) {
+    __shared__ uint32_t brow[GB_ROWS * GB_PITCH];
+    __shared__ float dsf[GB_ROWS];
+    __shared__ int bsh[GB_ROWS];                   // bit position of (row, tn = 0); tn lowers it by 4
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * GB_ROWS, n0 = blockIdx.y * GB_COLS;
+    if (tid < GB_ROWS) {
+        const int r = r0 + tid;
+        const int m = r < R ? rows[r] : 0;
+        dsf[tid] = r < R ? ds[m] : 0.f;
+        bsh[tid] = relu_bit_pos(m, 0);
     }
-    // column partials: block = 64 columns of [dw2 | db1]; thread (tx, ty): column tx, row-tiles t = ty mod 4
-    __shared__ float red[4][64];
-    const int cb = blockIdx.x - nblk_dw1;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = cb * 64 + tx;                  // 0 .. 2d-1
-    const int which = col / d, c = col % d;
-    float a = 0.f;
-    {
-        const float* cp = colpart + (int64_t)which * nbm * d + c;
-        int t = ty;
-        for (; t + 12 < nbm; t += 16) {
-            const float v0 = cp[(int64_t)(t + 0) * d], v1 = cp[(int64_t)(t + 4) * d];
-            const float v2 = cp[(int64_t)(t + 8) * d], v3 = cp[(int64_t)(t + 12) * d];
-            a += v0;
-            a += v1;
-            a += v2;
-            a += v3;
+    {       // 128 B of bits per row: thread -> (row, 16-byte piece p of 8): wave column p / 4, lanes c = 4 (p % 4) .. +3
+        const int row = tid >> 3, p8 = tid & 7;
+        for (int rr = row; rr < GB_ROWS; rr += 32) {
+            const int r = r0 + rr;
+            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+            if (r < R) v = *(const u32x4*)(bits + relu_bit_dword(rows[r], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
+            uint32_t* dstw = brow + rr * GB_PITCH + p8 * 4;
+            dstw[0] = v[0];
+            dstw[1] = v[1];
+            dstw[2] = v[2];
+            dstw[3] = v[3];
         }
-        for (; t < nbm; t += 4) a += cp[(int64_t)t * d];
     }
-    red[ty][tx] = a;
     __syncthreads();
-    if (ty == 0) {
-        const float sum = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-        (which ? db1 : dw2)[c] = sum;
+    // column nl (0..127) of the block: dword (nl >> 6) * 16 + (nl & 15) of the row, bit bsh[row] - 4 * ((nl >> 4) & 3)
+    // pass 1: G' row-major, 16 B (8 columns) per thread and step
+    if (G) {
+#pragma unroll
+        for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 4, cb = c & 15;                       // columns 8 cb .. 8 cb + 7
+            const uint32_t* w = brow + row * GB_PITCH + (cb >> 3) * 16 + (cb & 1) * 8;
+            const int sh = bsh[row] - 4 * ((cb >> 1) & 3);
+            const __bf16 dv = (__bf16)dsf[row];
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = ((w[k] >> sh) & 1u) ? dv : (__bf16)0.f;
+            *(bf16x8*)(G + (int64_t)(r0 + row) * d + n0 + cb * 8) = o;
+        }
     }
-    if (cb == 0 && ty == 1) {                      // db2: one wave, lane-strided partial sums, then a fixed tree
+    // pass 2: G'^T, 16 B (8 rows of one column) per thread and step; 8 neighbouring lanes cover the 64 rows of a
+    // column, and their fp32 partial sums (lane order, then a fixed xor tree) give the block's column sum
+#pragma unroll
+    for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
+        const int c = tid + i * 256;
+        const int nl = c >> 3, q8 = c & 7;
+        const int wofs = (nl >> 6) * 16 + (nl & 15), tsh = 4 * ((nl >> 4) & 3);
+        bf16x8 o;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = q8 * 8 + k;
+            const bool on = (brow[row * GB_PITCH + wofs] >> (bsh[row] - tsh)) & 1u;
+            const float v = dsf[row];
+            o[k] = on ? (__bf16)v : (__bf16)0.f;
+            acc += on ? v : 0.f;
+        }
+        *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (q8 == 0) colpart[(int64_t)blockIdx.x * d + n0 + nl] = acc;
+    }
+    if (blockIdx.y == 0 && tid < 64) {
+        float v = dsf[tid];
+        v = wave_sum(v);
+        if (tid == 0) dspart[blockIdx.x] = v;
+    }
+}
+
+// One workgroup per output row n of W1:  U[n][:] = sum of the split-K slabs;  c[n] = sum of the column partials;
+//   dW1[n][:] = w2[n] * U[n][:]     db1[n] = w2[n] * c[n]     dw2[n] = <W1[n][:], U[n][:]> + b1[n] * c[n]
+// (relu(h) = h * relu'(h), so sum_m ds[m] relu(h[m][n]) = <W1[n], U[n]> + b1[n] c[n]: no H needed);  db2 = sum ds.
+// Fixed summation orders: bitwise reproducible.
+__global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __restrict__ slab, int splits, int d,
+                                                                const __bf16* __restrict__ w1, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2,
+                                                                const float* __restrict__ colpart,
+                                                                const float* __restrict__ dspart, int nblk,
+                                                                float* __restrict__ dw1, float* __restrict__ dw2,
+                                                                float* __restrict__ db1, float* __restrict__ db2) {
+    __shared__ float red[4], red2[4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t dd = (int64_t)d * d;
+    const float wn = w2[n];
+    float dot = 0.f;
+    for (int k = tid * 4; k < d; k += 1024) {
+        const int64_t i = (int64_t)n * d + k;
+        // four slabs per round: their loads are independent and in flight together; the order stays fixed
+        f32x4 u = *(const f32x4*)(slab + i);
+        int sidx = 1;
+        for (; sidx + 3 < splits; sidx += 4) {
+            const f32x4 v0 = *(const f32x4*)(slab + (int64_t)(sidx + 0) * dd + i);
+            const f32x4 v1 = *(const f32x4*)(slab + (int64_t)(sidx + 1) * dd + i);
+            const f32x4 v2 = *(const f32x4*)(slab + (int64_t)(sidx + 2) * dd + i);
+            const f32x4 v3 = *(const f32x4*)(slab + (int64_t)(sidx + 3) * dd + i);
+            u += v0;
+            u += v1;
+            u += v2;
+            u += v3;
+        }
+        for (; sidx < splits; ++sidx) u += *(const f32x4*)(slab + (int64_t)sidx * dd + i);
+        const bf16x4 wv = *(const bf16x4*)(w1 + i);
+        dot += ((float)wv[0] * u[0] + (float)wv[1] * u[1]) + ((float)wv[2] * u[2] + (float)wv[3] * u[3]);
+        *(f32x4*)(dw1 + i) = u * wn;
+    }
+    float c = 0.f;
+    for (int t = tid; t < nblk; t += 256) c += colpart[(int64_t)t * d + n];
+    dot = wave_sum(dot);
+    c = wave_sum(c);
+    if (lane == 0) {
+        red[wid] = dot;
+        red2[wid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float dsum = (red[0] + red[1]) + (red[2] + red[3]);
+        const float csum = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+        dw2[n] = dsum + b1[n] * csum;
+        db1[n] = wn * csum;
+    }
+    if (n == 0 && wid == 1) {                      // db2: one wave, lane-strided partial sums, then a fixed tree
         float s2 = 0.f;
-        for (int t = tx; t < nbm; t += 64) s2 += colpart[(int64_t)2 * nbm * d + t];
+        for (int t = lane; t < nblk; t += 64) s2 += dspart[t];
         s2 = wave_sum(s2);
-        if (tx == 0) db2[0] = s2;
+        if (lane == 0) db2[0] = s2;
     }
 }
 
@@ -688,7 +713,6 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     bool ok = true;
     switch (epi) {
         case EPI_SCORE: ok = reserve_lds_once(once[0], (const void*)gemm_nt_kernel<EPI_SCORE>, SCORE_LDS); break;
-        case EPI_DH: ok = reserve_lds_once(once[1], (const void*)gemm_nt_kernel<EPI_DH>, EPI_LDS); break;
         case EPI_SLAB: ok = reserve_lds_once(once[2], (const void*)gemm_nt_kernel<EPI_SLAB>, GEMM_LDS); break;
         default: ok = reserve_lds_once(once[3], (const void*)gemm_nt_kernel<EPI_ROWS>, EPI_LDS); break;
     }
@@ -709,7 +733,6 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
             hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
             break;
         }
-        case EPI_DH: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DH>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
         default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
     }
@@ -764,9 +787,16 @@ extern "C" size_t star_scorer_fwd_workspace(int64_t N, int d) {
     return align256((size_t)((d + BN - 1) / BN) * (size_t)round_up(N, BM) * sizeof(float));
 }
 
+extern "C" size_t star_scorer_relu_bits_bytes(int64_t N, int d) {
+    using namespace star;
+    if (N <= 0 || d <= 0) return 0;
+    // one 8-KiB blob per 256 x 256 output tile of the forward GEMM (column tiles padded to 256)
+    return (size_t)(round_up(N, BM) / BM) * (size_t)((d + BN - 1) / BN) * (size_t)(BM * BN / 8);
+}
+
 extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
-                               int64_t N, int d, float* scores, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               int64_t N, int d, float* scores, void* relu_bits, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     using namespace star;
     STAR_REQUIRE(x && w1 && b1 && w2 && b2 && scores && workspace, "star_scorer_fwd: null pointer");
     STAR_REQUIRE(N >= 1 && N < (1ll << 31) - BM, "star_scorer_fwd: bad N=%lld", (long long)N);
@@ -788,6 +818,8 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
     p.w2 = w2;
     p.partial = (float*)workspace;
     p.partial_ld = round_up(N, BM);
+    STAR_REQUIRE(((uintptr_t)relu_bits & 15) == 0, "star_scorer_fwd: relu_bits must be 16-byte aligned");
+    p.relu_bits = (uint32_t*)relu_bits;
     hipStream_t st = (hipStream_t)stream;
     if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;
     hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
@@ -797,7 +829,8 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
 }
 
 extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2,
-                                      const float* b2, int64_t N, int d, float* scores, void* stream) {
+                                      const float* b2, int64_t N, int d, float* scores, void* relu_bits,
+                                      void* stream) {
     using namespace star;
     STAR_REQUIRE(N >= 1 && d >= 128 && d % 128 == 0, "star_scorer_fwd_static: bad shape N=%lld d=%d", (long long)N, d);
     const size_t need = star_scorer_fwd_workspace(N, d);
@@ -810,44 +843,71 @@ extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float
     void* ptr = static_scratch(&rc);
     if (!ptr) return rc;
     // every partial the finish kernel reads is written by the GEMM of THIS call: nothing has to start at zero
-    return star_scorer_fwd(x, w1, b1, w2, b2, N, d, scores, ptr, STATIC_SCRATCH_BYTES, stream);
+    return star_scorer_fwd(x, w1, b1, w2, b2, N, d, scores, relu_bits, ptr, STATIC_SCRATCH_BYTES, stream);
 }
+
+namespace star {
+struct BwdLayout {
+    int64_t Rpad;
+    int nblk, splits;
+    size_t g_off, gt_off, xt_off, col_off, ds_off, slab_off, total;
+};
+static BwdLayout bwd_layout(int64_t R, int d, bool want_dx) {
+    BwdLayout L;
+    L.Rpad = round_up(R, BM);
+    L.nblk = (int)(L.Rpad / GB_ROWS);
+    L.splits = bwd_splits(d);
+    const size_t gbytes = align256((size_t)L.Rpad * d * 2);
+    size_t off = 0;
+    L.g_off = off;
+    off += want_dx ? gbytes : 0;
+    L.gt_off = off;
+    off += gbytes;
+    L.xt_off = off;
+    off += gbytes;
+    L.col_off = off;
+    off += align256((size_t)L.nblk * d * 4);
+    L.ds_off = off;
+    off += align256((size_t)L.nblk * 4);
+    L.slab_off = off;
+    off += align256((size_t)L.splits * d * d * 4);
+    L.total = off;
+    return L;
+}
+}  // namespace star
 
 extern "C" size_t star_scorer_bwd_workspace(int64_t R, int d) {
     using namespace star;
     if (R <= 0 || d <= 0) return 0;
-    const int64_t Rpad = round_up(R, BM);
-    const int nbm = (int)(Rpad / BM);
-    size_t g = align256((size_t)Rpad * d * 2);
-    return 3 * g + align256(((size_t)2 * nbm * d + nbm) * 4) + align256((size_t)bwd_splits(d) * d * d * 4);
+    return bwd_layout(R, d, true).total;
 }
 
-extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, const float* b1, const float* w2,
-                               const float* dscores, const int32_t* rows, int64_t R, int64_t N, int d, float* dw1,
-                               float* db1, float* dw2, float* db2, void* dx, int dx_zeroed, void* workspace,
-                               size_t workspace_bytes, void* stream, void* aux_stream,
+extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, const float* b1, const float* w2,
+                               const void* relu_bits, const float* dscores, const int32_t* rows, int64_t R, int64_t N,
+                               int d, float* dw1, float* db1, float* dw2, float* db2, void* dx, int dx_zeroed,
+                               void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
                                void* const* aux_events_host) {
     using namespace star;
-    STAR_REQUIRE(x && w1 && b1 && w2 && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
+    STAR_REQUIRE(x && w1 && b1 && w2 && relu_bits && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
                  "star_scorer_bwd: null pointer");
-    STAR_REQUIRE(!dx || w1t, "star_scorer_bwd: dx requested without w1t");
+    STAR_REQUIRE(!dx || w1ts, "star_scorer_bwd: dx requested without w1ts");
     STAR_REQUIRE(R >= 1 && R <= N && N < (1ll << 31) - BM, "star_scorer_bwd: bad R=%lld N=%lld", (long long)R, (long long)N);
     STAR_REQUIRE(d >= 128 && d % 128 == 0, "star_scorer_bwd: d=%d must be a multiple of 128", d);
+    STAR_REQUIRE(((uintptr_t)relu_bits & 15) == 0, "star_scorer_bwd: relu_bits must be 16-byte aligned");
     if (workspace_bytes < star_scorer_bwd_workspace(R, d)) {
         set_error("star_scorer_bwd: workspace %zu < %zu bytes", workspace_bytes, star_scorer_bwd_workspace(R, d));
         return STAR_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int64_t Rpad = round_up(R, BM);
-    const int nbm = (int)(Rpad / BM);
-    const int splits = bwd_splits(d);
+    const BwdLayout L = bwd_layout(R, d, dx != nullptr);
+    const int64_t Rpad = L.Rpad;
     uint8_t* ws = (uint8_t*)workspace;
-    const size_t gbytes = align256((size_t)Rpad * d * 2);
-    __bf16* G = (__bf16*)ws;
-    __bf16* GT = (__bf16*)(ws + gbytes);
-    __bf16* XT = (__bf16*)(ws + 2 * gbytes);
-    float* colpart = (float*)(ws + 3 * gbytes);
-    float* slab = (float*)(ws + 3 * gbytes + align256(((size_t)2 * nbm * d + nbm) * 4));
+    __bf16* G = dx ? (__bf16*)(ws + L.g_off) : nullptr;
+    __bf16* GT = (__bf16*)(ws + L.gt_off);
+    __bf16* XT = (__bf16*)(ws + L.xt_off);
+    float* colpart = (float*)(ws + L.col_off);
+    float* dspart = (float*)(ws + L.ds_off);
+    float* slab = (float*)(ws + L.slab_off);
 
     // Two independent chains: the MFMA-bound GEMMs stay on `stream`; the memory-bound helpers (zero-fill of dx,
     // X_sel^T, the slab / column reductions) run beside them on `aux_stream` when the caller provides one.
@@ -880,28 +940,12 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
                        (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
     if (aux != st) STAR_HIP(hipEventRecord(ev_join[0], aux));
-    // 1. recompute H for the listed rows, emit G = dH and G^T, column partials for dw2 / db1
-    GemmParams p = {};
-    p.A = (const __bf16*)x;
-    p.B = (const __bf16*)w1;
-    p.lda = d;
-    p.ldb = d;
-    p.M = (int)Rpad;
-    p.N = d;
-    p.kchunks = d / BK;
-    p.splits = 1;
-    p.a_rows = rows;
-    p.a_rows_n = (int)R;
-    p.b1 = b1;
-    p.w2 = w2;
-    p.ds = dscores;
-    p.G = dx ? G : nullptr;
-    p.GT = GT;
-    p.ldgt = Rpad;
-    p.colpart = colpart;
-    if (int rc = launch_gemm(EPI_DH, p, st)) return rc;
+    // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials
+    static_assert(GB_COLS == 128, "d is a multiple of 128");
+    hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk, d / GB_COLS), dim3(256), 0, st, (const uint32_t*)relu_bits,
+                       (d + BN - 1) / BN, dscores, rows, (int)R, (int)Rpad, d, G, GT, colpart, dspart);
     if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));
-    // 2. dW1 = G^T . X_sel  (split-K slabs)
+    // 2. U = G'^T . X_sel  (split-K slabs)
     GemmParams q = {};
     q.A = GT;
     q.B = XT;
@@ -910,24 +954,23 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     q.M = d;
     q.N = d;
     q.kchunks = (int)(Rpad / BK);
-    q.splits = splits;
+    q.splits = L.splits;
     q.slab = slab;
     if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
-    // 3. reductions (on aux, beside the dX GEMM)
+    // 3. reductions: dW1 = diag(w2) U, dw2, db1, db2 (on aux, beside the dX GEMM)
     if (aux != st) {
         STAR_HIP(hipEventRecord(ev_fork[1], st));
         STAR_HIP(hipStreamWaitEvent(aux, ev_fork[1], 0));
     }
-    const int64_t dd = (int64_t)d * d;
-    const int nblk_dw1 = cdiv(dd, 1024);
-    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(nblk_dw1 + 2 * d / 64), dim3(256), 0, aux, (const float*)slab,
-                       splits, dd, dw1, (const float*)colpart, nbm, d, dw2, db1, db2, nblk_dw1);
+    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(d), dim3(256), 0, aux, (const float*)slab, L.splits, d,
+                       (const __bf16*)w1, b1, w2, (const float*)colpart, (const float*)dspart, L.nblk, dw1, dw2, db1,
+                       db2);
     if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
-    // 4. dX rows = G . W1
+    // 4. dX rows = G' . (diag(w2) W1)
     if (dx) {
         GemmParams r = {};
         r.A = G;
-        r.B = (const __bf16*)w1t;
+        r.B = (const __bf16*)w1ts;
         r.lda = d;
         r.ldb = d;
         r.M = (int)Rpad;
@@ -946,7 +989,8 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1t, c
     return STAR_OK;
 }
 
-extern "C" int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, void* stream) {
+extern "C" int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t,
+                                        const float* t_scale, void* stream) {
     using namespace star;
     STAR_REQUIRE(src && (dst || dst_t), "star_cast_transpose_bf16: null pointer");
     STAR_REQUIRE(rows >= 1 && cols >= 1, "star_cast_transpose_bf16: bad shape %d x %d", rows, cols);
@@ -954,10 +998,10 @@ extern "C" int star_cast_transpose_bf16(const float* src, int rows, int cols, vo
                       ((uintptr_t)dst_t % 16 == 0);
     if (fast)
         hipLaunchKernelGGL(cast_transpose_kernel, dim3(cols / 64, rows / 64), dim3(256), 0, (hipStream_t)stream, src,
-                           rows, cols, (__bf16*)dst, (__bf16*)dst_t);
+                           rows, cols, (__bf16*)dst, (__bf16*)dst_t, t_scale);
     else
         hipLaunchKernelGGL(cast_transpose_generic_kernel, dim3(cdiv(cols, 64), cdiv(rows, 64)), dim3(256), 0,
-                           (hipStream_t)stream, src, rows, cols, (__bf16*)dst, (__bf16*)dst_t);
+                           (hipStream_t)stream, src, rows, cols, (__bf16*)dst, (__bf16*)dst_t, t_scale);
     STAR_LAUNCH_CHECK("star_cast_transpose_bf16");
     return STAR_OK;
 }

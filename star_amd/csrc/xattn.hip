@@ -141,6 +141,26 @@ struct Drop {
     }
 };
 
+// ---- in-kernel time stamps (diagnostic builds only: -DSTAR_XA_STAMP; the product library has none)
+#ifdef STAR_XA_STAMP
+__device__ unsigned long long xa_stamps[1024 * 16];
+#define XA_STAMP(slot)                                                                                             \
+    do {                                                                                                           \
+        if (threadIdx.x == 0)                                                                                      \
+            xa_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 16 + (slot)] =     \
+                __builtin_amdgcn_s_memrealtime();                                                                  \
+    } while (0)
+#define XA_STAMP_T(slot, T)                                                                                        \
+    do {                                                                                                           \
+        if (threadIdx.x == (T))                                                                                    \
+            xa_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 16 + (slot)] =     \
+                __builtin_amdgcn_s_memrealtime();                                                                  \
+    } while (0)
+#else
+#define XA_STAMP(slot) do {} while (0)
+#define XA_STAMP_T(slot, T) do {} while (0)
+#endif
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_THR = 8.0f;   // log2 units: the running max is only raised when a tile exceeds it by 2^8
@@ -574,18 +594,42 @@ __device__ __forceinline__ void xa_glds4(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
-// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform)
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform; the immediate of
+// s_waitcnt must be a constant, hence the switch; counts above 32 wait for 32, which is only ever stricter)
 __device__ __forceinline__ void xa_wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    switch (n > 32 ? 32 : n) {
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -616,15 +660,17 @@ __device__ __forceinline__ void xa_wait_lds() {
 #define XA_GLOAD4_ASYNC(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 
 // issue the DMA of K / V / bias tile `tile` (keys tile*64 ..) into ring slot tile % NST
-template <int HD>
+template <int HD, int NW = 8>
 __device__ __forceinline__ void ring_stage(uint8_t* smem, const __bf16* Kb, int64_t k_sr, const __bf16* Vb, int64_t v_sr,
                                            const float* bias_row, int bias_len, int Kn, int tile, int wid, int lane) {
     using R = Ring<HD>;
+    constexpr int PIECES = R::TILE / 1024 / NW;      // 1-KiB DMA pieces per loading wave per operand tile
+    static_assert(PIECES >= 1, "tile too small for this many loader waves");
     uint8_t* st = smem + (tile % R::NST) * R::STAGE;
     const int key0 = tile * R::KT2;
 #pragma unroll
-    for (int i = 0; i < R::PIECES; ++i) {
-        const int piece = wid * R::PIECES + i;
+    for (int i = 0; i < PIECES; ++i) {
+        const int piece = wid * PIECES + i;
         const int row = piece * R::RPP + lane / (R::ROWB / 16);
         const int pos = lane % (R::ROWB / 16);
         const int chunk = pos ^ R::swz(row & 15);
@@ -637,6 +683,259 @@ __device__ __forceinline__ void ring_stage(uint8_t* smem, const __bf16* Kb, int6
         const int key = min(key0 + lane, max(bias_len, 1) - 1);
         xa_glds4(bias_row + key, st + 2 * R::TILE);
     }
+}
+
+// ---- forward on the same ring (HD = 64 or 128).  The register-staged forward above keeps ONE K / V step in flight and
+// every workgroup of the launch walks its steps in lock step (one workgroup per CU at the usual shapes), so HBM idles
+// while the chip computes and the other way round; and an LDS-DMA piece costs the wave that issues it 100-200 issue
+// cycles, which a wave that also computes pays on its critical path.  Here the roles are split: 8 waves =
+//   4 consumer waves x 32 queries = two 16-query blocks that share every K / V fragment read from LDS (LDS read
+//     bandwidth is what bounds the tile loop: eight waves x 16 queries re-read each tile twice as often and took
+//     1.2 us per 64 keys) (16x16x32 MFMAs, query on the MFMA column): S^T = K Q^T (A rows from LDS, B = Q
+//     fragments in registers); online softmax in the log2 domain with a lazily raised running max (the usual tile
+//     needs neither a cross-lane max nor a rescale); the bf16 P^T block is packed in-lane into the B operand of
+//     O^T = V^T P^T (A by ds_read_b64_tr_b16 of the V tile, same key permutation on both sides); no merge step;
+//   4 loader waves (one per SIMD) that stream the K / V / bias tiles of 64 keys through the 4-slot ring: four tiles
+//     (128 KiB at HD = 128, more than half of a 375-key memory) are requested before the first MFMA and three stay in
+//     flight behind every barrier.
+// One raw barrier per tile joins them: a loader arrives once its pieces of the tile have landed (counted vmcnt), a
+// consumer once it has finished the previous tile, whose slot the loaders refill right after the barrier.
+constexpr int FR_CONSUMERS = 4, FR_LOADERS = 4, FR_THREADS = (FR_CONSUMERS + FR_LOADERS) * 64;
+constexpr int FR_NQ = 2;          // 16-query blocks per consumer wave (they share every K / V fragment read from LDS)
+
+template <int HD, bool HAS_BIAS, bool DROP>
+__global__ __launch_bounds__(FR_THREADS) void xattn_fwd_ring_kernel(
+    const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
+    const float* __restrict__ bias, const float* __restrict__ zero_bias, const int32_t* __restrict__ key_len,
+    star_xattn_shape s, __bf16* __restrict__ O, float* __restrict__ lse) {
+    using R = Ring<HD>;
+    constexpr int ROWB = R::ROWB, KT2 = R::KT2;
+    constexpr int KS = HD / 32;       // k-steps of a 16x16x32 MFMA over the head dim
+    constexpr int NT = HD / 16;       // 16-wide head-dim tiles of O^T
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+
+    int kend = s.Kn;
+    if (key_len) kend = min(kend, key_len[b]);
+    int kloop_wg = kend;                             // keys the workgroup has to visit
+    if (s.ilk_diag >= 0) kloop_wg = min(kend, min((int)blockIdx.x * 128 + 128, s.L) + s.ilk_diag);
+    const int ntiles = (kloop_wg + KT2 - 1) / KT2;
+    XA_STAMP(0);
+#ifdef STAR_XA_STAMP
+    if (threadIdx.x == 0) xa_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 16 + 7] = __builtin_amdgcn_s_memtime();
+#endif
+
+    if (wid >= FR_CONSUMERS) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wid - FR_CONSUMERS;
+        const __bf16* Kb = K + (int64_t)b * s.k_sb + (int64_t)h * s.k_sh;
+        const __bf16* Vb = V + (int64_t)b * s.v_sb + (int64_t)h * s.v_sh;
+        const float* bias_row = HAS_BIAS ? bias + (int64_t)b * s.bias_len : zero_bias;
+        const int bias_len = HAS_BIAS ? s.bias_len : 0;
+        const int ppt = 2 * (R::TILE / 1024 / FR_LOADERS) + (lw == 0 ? 1 : 0);      // DMA operations of this wave per tile
+        XA_STAMP_T(8, FR_CONSUMERS * 64);
+        // tiles 0 and 1 first; the first barrier falls as soon as tile 0 has landed (the first DMAs of a launch are
+        // slow to issue -- cold address translation -- so filling all four slots first would hold the consumers back)
+#pragma unroll 1
+        for (int t = 0; t < min(ntiles, 2); ++t) {
+            ring_stage<HD, FR_LOADERS>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, t, lw, lane);
+            XA_STAMP_T(9 + t, FR_CONSUMERS * 64);
+        }
+#pragma unroll 1
+        for (int tile = 0; tile < ntiles; ++tile) {
+            // tile `tile` has landed once only the DMAs of the younger tiles are outstanding: tile 1 at tile 0, two
+            // tiles afterwards (2 and 3 are issued behind the first barrier, tile + 3 behind every later one)
+            xa_wait_vm(ppt * min(tile == 0 ? 1 : 2, ntiles - 1 - tile));
+            if (tile == 0) XA_STAMP_T(13, FR_CONSUMERS * 64);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // slot (tile+3) % 4 held tile-1, which every consumer finished before the barrier above
+            if (tile == 0) {
+                if (ntiles > 2) ring_stage<HD, FR_LOADERS>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, 2, lw, lane);
+                if (ntiles > 3) ring_stage<HD, FR_LOADERS>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, 3, lw, lane);
+            } else if (tile + 3 < ntiles) {
+                ring_stage<HD, FR_LOADERS>(smem, Kb, s.k_sr, Vb, s.v_sr, bias_row, bias_len, s.Kn, tile + 3, lw, lane);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 128 + wid * (16 * FR_NQ);      // first query of this wave
+    const int bias_len = HAS_BIAS ? s.bias_len : 0;
+    const Drop<DROP> drop(s, b, h);
+    int kloop = kend;                                // keys this wave has to visit
+    if (s.ilk_diag >= 0) kloop = min(kend, min(q0 + 16 * FR_NQ, s.L) + s.ilk_diag);
+    if (q0 >= s.L) kloop = 0;
+
+    bf16x8 qf[FR_NQ][KS];
+    int qi[FR_NQ], klim[FR_NQ], klim_wave[FR_NQ];
+#pragma unroll
+    for (int qb = 0; qb < FR_NQ; ++qb) {
+        const int q = q0 + 16 * qb + r16;
+        qi[qb] = q;
+        const __bf16* qrow = Q + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)min(q, s.L - 1) * s.q_sr + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = *(const bf16x8*)(qrow + ks * 32);
+        // per-lane visibility limit: key visible  <=>  key < klim
+        int kl = kend;
+        if (s.ilk_diag >= 0) kl = min(kl, q + s.ilk_diag + 1);
+        if (q >= s.L) kl = 0;
+        klim[qb] = kl;
+        // every lane of the block sees all keys below klim_wave (0: rows past L -> always the masked path)
+        int kw = kend;
+        if (s.ilk_diag >= 0) kw = min(kw, q0 + 16 * qb + s.ilk_diag + 1);
+        if (q0 + 16 * qb + 16 > s.L) kw = 0;
+        klim_wave[qb] = kw;
+    }
+    const float scale2 = s.scale * LOG2E;
+
+    f32x4 oacc[FR_NQ][NT];
+    float m_run[FR_NQ], l_run[FR_NQ];
+#pragma unroll
+    for (int qb = 0; qb < FR_NQ; ++qb) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) oacc[qb][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[qb] = NEG_SENTINEL;
+        l_run[qb] = 0.f;
+    }
+
+    const int sw_row = R::swz(r16);
+    const int tr_row = 4 * g + (r16 >> 2);
+    const int sw_tr = R::swz(tr_row);
+
+#pragma unroll 1
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        XA_STAMP(1 + tile);
+        const uint8_t* k_lds = smem + (tile % R::NST) * R::STAGE;
+        const uint8_t* v_lds = k_lds + R::TILE;
+        const float* b_lds = (const float*)(k_lds + 2 * R::TILE);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb0 = tile * KT2 + sub * 32;
+            if (kb0 >= kloop) break;                  // wave-uniform
+            bf16x8 ka[2][KS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rowoff = (sub * 32 + 16 * t + r16) * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ka[t][ks] = lds_row8(k_lds + rowoff + (((4 * ks + g) ^ sw_row) << 4));
+            }
+            f32x4 bb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bb[t] = *(const f32x4*)(b_lds + sub * 32 + 16 * t + 4 * g);
+            // transposed V fragments: in flight during the S^T products and the softmax arithmetic
+            const uint8_t* trp = v_lds + (sub * 32 + tr_row) * ROWB + 8 * (lane & 1);
+            bf16x8 vt[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint8_t* p0 = trp + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                vt[nt] = lds_tr8(p0, p0 + 16 * ROWB);
+            }
+            f32x4 sacc[FR_NQ][2];
+#pragma unroll
+            for (int qb = 0; qb < FR_NQ; ++qb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) sacc[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int qb = 0; qb < FR_NQ; ++qb)
+                        sacc[qb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[t][ks], qf[qb][ks], sacc[qb][t], 0, 0, 0);
+            bf16x8 pf[FR_NQ];
+#pragma unroll
+            for (int qb = 0; qb < FR_NQ; ++qb) {
+                // logits in the log2 domain; masks only where a step needs them
+                const bool plain = (kb0 + 32 <= klim_wave[qb]) && (!HAS_BIAS || kb0 + 32 <= bias_len);    // wave-uniform
+                float lg[8];
+                if (plain) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            lg[4 * t + j] = HAS_BIAS ? __builtin_fmaf(sacc[qb][t][j], scale2, bb[t][j] * LOG2E)
+                                                     : sacc[qb][t][j] * scale2;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int key = kb0 + 16 * t + 4 * g + j;
+                            const float bj = (HAS_BIAS && key < bias_len) ? bb[t][j] * LOG2E : 0.f;
+                            const float v = sacc[qb][t][j] * scale2 + bj;
+                            lg[4 * t + j] = (key < klim[qb]) ? v : -INFINITY;
+                        }
+                }
+                float mx = NEG_SENTINEL;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, lg[i]);
+                // lazy rescale: the running max (common to the four lane groups of a query) is raised only when some
+                // lane exceeds it by 2^RESCALE_THR -- the usual step needs neither a cross-lane max nor a rescale
+                if (!__all(mx <= m_run[qb] + RESCALE_THR)) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run[qb], mx);
+                    const float alpha = exp2f(m_run[qb] - m_new);
+                    l_run[qb] *= alpha;
+                    m_run[qb] = m_new;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) oacc[qb][nt][j] *= alpha;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float p = __builtin_amdgcn_exp2f(lg[i] - m_run[qb]);
+                    psum += p;
+                    // the softmax denominator is that of the undropped weights; only P V sees the mask
+                    if constexpr (DROP) p = drop.keep(qi[qb], kb0 + 16 * (i >> 2) + 4 * g + (i & 3)) ? p : 0.f;
+                    pf[qb][i] = (__bf16)p;
+                }
+                l_run[qb] += psum;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int qb = 0; qb < FR_NQ; ++qb)
+                    oacc[qb][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[nt], pf[qb], oacc[qb][nt], 0, 0, 0);
+        }
+    }
+
+    XA_STAMP(14);
+#pragma unroll
+    for (int qb = 0; qb < FR_NQ; ++qb) {
+        float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 16, 64);
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if constexpr (DROP) inv *= drop.inv_keep;
+        const int q = qi[qb];
+        if (q < s.L) {
+            __bf16* orow = O + (int64_t)b * s.o_sb + (int64_t)h * s.o_sh + (int64_t)q * s.o_sr + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = (__bf16)(oacc[qb][nt][j] * inv);
+                *(bf16x4*)(orow + nt * 16) = o4;
+            }
+            // natural-log LSE of the masked, biased logits
+            if (g == 0) lse[((int64_t)b * s.h + h) * s.L + q] = l_tot > 0.f ? (m_run[qb] + __log2f(l_tot)) * LN2 : 0.f;
+        }
+    }
+#ifdef STAR_XA_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XA_STAMP(15);
+    if (threadIdx.x == 0) xa_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 16 + 12] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <int HD, bool HAS_BIAS, bool DROP>
@@ -1335,6 +1634,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
     const int ngroups = (s.Kn + 15) >> 4;
     const int nrounds = (s.Kn + F::KROWS - 1) / F::KROWS;
 
+    XA_STAMP(0);
     // first group's K / V fragments: issued before the Q / dO staging so that both are in flight together
     bf16x8 kfr[KS], vfr[KS];
     float bias_cur = 0.f;
@@ -1376,6 +1676,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         if (tid < QROWS) lse_lds[tid] = lreg;
     }
     __syncthreads();
+    XA_STAMP(1);
 
     const int nslices = (s.L + 31) >> 5;
     const int sw_row = C::swz(r16);                               // row reads: row = 16t + r16
@@ -1565,7 +1866,9 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
             if (bias && nkey < s.bias_len) bias_cur = bias[(int64_t)b * s.bias_len + nkey];
         }
 
+        XA_STAMP(2 + 4 * (rnd & 3));
         xa_lds_barrier();          // K rows and dS of the whole round are in LDS
+        XA_STAMP(3 + 4 * (rnd & 3));
 
         // phase C: this wave's 16 queries against the round's keys
         if (wave_has_q) {
@@ -1597,7 +1900,9 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
         db += __shfl_xor(db, 32, 64);
         if (dbias_part && g == 0 && key < s.Kn) dbias_part[((int64_t)b * s.h + h) * s.Kn + key] = db;
 
+        XA_STAMP(4 + 4 * (rnd & 3));
         xa_lds_barrier();      // phase C reads done: the round's LDS rows are free again
+        XA_STAMP(5 + 4 * (rnd & 3));
 
         // dK / dV of the round leave through the wave's own 16 rows of the K and dS tiles (free until the next
         // round's writes, which follow in program order): accumulator layout -> row-major, so that every store
@@ -1656,6 +1961,11 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
             if (q < s.L) *(u32x4*)(dQ + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)q * s.q_sr + c * 8) = x;
         }
     }
+#ifdef STAR_XA_STAMP
+    XA_STAMP(14);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XA_STAMP(15);
+#endif
 }
 
 // dbias[b,j] (+)= sum_h dbias_part[b,h,j]   (fixed order over heads)
@@ -1770,14 +2080,37 @@ static int launch_fwd_ng(const void* q, const void* k, const void* v, const floa
     return STAR_OK;
 }
 
+template <int HD, bool HAS_BIAS, bool DROP>
+static int launch_fwd_ring(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
+                           const star_xattn_shape* s, void* o, float* lse, hipStream_t st) {
+    const int smem = Ring<HD>::BYTES;
+    XA_RESERVE((xattn_fwd_ring_kernel<HD, HAS_BIAS, DROP>), smem, "star_xattn_fwd");
+    // without a bias the DMA of the bias slot reads `lse` (any valid floats: never used)
+    hipLaunchKernelGGL((xattn_fwd_ring_kernel<HD, HAS_BIAS, DROP>), dim3(cdiv(s->L, 128), s->h, s->B), dim3(FR_THREADS), smem,
+                       st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, bias, (const float*)lse, key_len, *s,
+                       (__bf16*)o, lse);
+    return STAR_OK;
+}
+
 template <int HD, bool DROP>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* bias, const int32_t* key_len,
                       const star_xattn_shape* s, void* o, float* lse, float* p_out, hipStream_t st) {
-    // more than one 64-key tile: split the keys over two wave groups (two waves per SIMD)
-    const int force = test_override(STAR_OVR_XA_NG);
-    const bool two = force ? (force == 2) : (s->Kn > KT);
-    int rc = two ? launch_fwd_ng<HD, 2, DROP>(q, k, v, bias, key_len, s, o, lse, st)
+    int rc = STAR_OK;
+    bool done = false;
+    if constexpr (HD == 64 || HD == 128) {
+        if (test_override(STAR_OVR_XA_FWD) != 1) {        // 1 = the register-staged kernel (test-only switch)
+            rc = (bias && s->bias_len > 0) ? launch_fwd_ring<HD, true, DROP>(q, k, v, bias, key_len, s, o, lse, st)
+                                           : launch_fwd_ring<HD, false, DROP>(q, k, v, bias, key_len, s, o, lse, st);
+            done = true;
+        }
+    }
+    if (!done) {
+        // more than one 64-key tile: split the keys over two wave groups (two waves per SIMD)
+        const int force = test_override(STAR_OVR_XA_NG);
+        const bool two = force ? (force == 2) : (s->Kn > KT);
+        rc = two ? launch_fwd_ng<HD, 2, DROP>(q, k, v, bias, key_len, s, o, lse, st)
                  : launch_fwd_ng<HD, 1, DROP>(q, k, v, bias, key_len, s, o, lse, st);
+    }
     if (rc) return rc;
     if (p_out) {
         const int64_t rows = (int64_t)s->B * s->h * s->L;
@@ -1949,3 +2282,10 @@ extern "C" int star_xattn_dbias_sum(const float* const* parts_host, int nl, int 
     STAR_LAUNCH_CHECK("star_xattn_dbias_sum");
     return STAR_OK;
 }
+
+#ifdef STAR_XA_STAMP
+// diagnostic builds only: copy the in-kernel time stamps (1024 workgroups x 16 slots) to the host
+extern "C" int star_debug_read_stamps(unsigned long long* out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(star::xa_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -2;
+}
+#endif

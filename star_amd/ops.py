@@ -455,19 +455,24 @@ class _Scorer(torch.autograd.Function):
         N = xb.shape[0]
         dev = xb.device
         w1f = w1.detach().to(torch.float32).contiguous()
-        w1b = torch.empty((d, d), dtype=torch.bfloat16, device=dev)
-        w1t = torch.empty((d, d), dtype=torch.bfloat16, device=dev)
-        check(lib().star_cast_transpose_bf16(ptr(w1f), d, d, ptr(w1b), ptr(w1t), stream_ptr()),
-              "star_cast_transpose_bf16")
         b1f = b1.detach().to(torch.float32).contiguous()
         w2f = w2.detach().to(torch.float32).contiguous().view(-1)
         b2f = b2.detach().to(torch.float32).contiguous().view(-1)
+        need_grad = any(ctx.needs_input_grad[:5])     # all False under no_grad / for detached inputs
+        need_dx = need_grad and ctx.needs_input_grad[0]
+        w1b = torch.empty((d, d), dtype=torch.bfloat16, device=dev)
+        # the backward's dX GEMM wants (diag(w2) W1)^T in bf16: written by the same pass as the bf16 copy of W1
+        w1ts = torch.empty((d, d), dtype=torch.bfloat16, device=dev) if need_dx else None
+        check(lib().star_cast_transpose_bf16(ptr(w1f), d, d, ptr(w1b), ptr(w1ts), ptr(w2f) if need_dx else None,
+                                             stream_ptr()), "star_cast_transpose_bf16")
         wsb = lib().star_scorer_fwd_workspace(N, d)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        # ReLU sign bits (1 bit per element of H): all the backward needs of the hidden activation
+        bits = torch.empty((lib().star_scorer_relu_bits_bytes(N, d),), dtype=torch.uint8, device=dev) if need_grad else None
         scores = torch.empty((N,), dtype=torch.float32, device=dev)
-        check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(ws),
-                                    wsb, stream_ptr()), "star_scorer_fwd")
-        ctx.save_for_backward(xb, w1b, w1t, b1f, w2f)
+        check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(bits),
+                                    ptr(ws), wsb, stream_ptr()), "star_scorer_fwd")
+        ctx.save_for_backward(xb, w1b, w1ts, b1f, w2f, bits)
         ctx.hint = hint
         ctx.forward_id = hint._begin_forward() if hint is not None else 0
         ctx.x_shape = x.shape
@@ -481,7 +486,7 @@ class _Scorer(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return None, None, None, None, None, None
-        xb, w1b, w1t, b1f, w2f = ctx.saved_tensors
+        xb, w1b, w1ts, b1f, w2f, bits = ctx.saved_tensors
         N, d = xb.shape
         dev = xb.device
         ds = g.to(torch.float32).contiguous().view(-1)
@@ -492,7 +497,7 @@ class _Scorer(torch.autograd.Function):
             rows = torch.arange(N, dtype=torch.int32, device=dev)
         rows = rows.to(torch.int32).contiguous().view(-1)
         R = rows.numel()
-        need_dx = ctx.needs_input_grad[0]
+        need_dx = ctx.needs_input_grad[0] and w1ts is not None
         dx = torch.empty((N, d), dtype=torch.bfloat16, device=dev) if need_dx else None   # zero-filled by the call
         dw1 = torch.empty((d, d), dtype=torch.float32, device=dev)
         db1 = torch.empty((d,), dtype=torch.float32, device=dev)
@@ -503,7 +508,7 @@ class _Scorer(torch.autograd.Function):
         # the fork/join costs four event operations on the host: worth it when the launches are replayed from a HIP
         # graph (no host cost at replay), not for eager launches, which are host-bound already
         aux = _aux_stream(dev) if torch.cuda.is_current_stream_capturing() else None
-        check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1t), ptr(b1f), ptr(w2f), ptr(ds), ptr(rows), R, N, d,
+        check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1ts), ptr(b1f), ptr(w2f), ptr(bits), ptr(ds), ptr(rows), R, N, d,
                                     ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0, ptr(ws), wsb, stream_ptr(),
                                     aux[0].cuda_stream if aux is not None else None,
                                     aux[2] if aux is not None else None), "star_scorer_bwd")
@@ -787,4 +792,4 @@ def test_override(which: int, value: int) -> int:
     return rc
 
 
-OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG = 0, 1, 2, 3
+OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG, OVR_XA_FWD = 0, 1, 2, 3, 4

@@ -42,9 +42,11 @@ def test_argument_errors_do_not_need_a_gpu():
     L = _lib.lib()
     rc = L.star_topk_select(None, None, None, None, 0.25, 1, 8, 2, None, None, None, None, None, None, None)
     assert rc == -1 and b"star_topk_select" in L.star_last_error()
-    rc = L.star_scorer_fwd(None, None, None, None, None, 10, 100, None, None, 0, None)
+    rc = L.star_scorer_fwd(None, None, None, None, None, 10, 100, None, None, None, 0, None)
     assert rc == -1
     assert L.star_scorer_fwd_workspace(48000, 1024) == 4 * 48128 * 4   # 4 column tiles x rows padded to 256
+    assert L.star_scorer_relu_bits_bytes(48000, 1024) == 48128 * 128     # one bit per element of H
+    assert L.star_scorer_relu_bits_bytes(300, 384) == 2 * 2 * 8192         # column tiles padded to 256
 
 
 def test_ops_refuse_cpu_tensors():

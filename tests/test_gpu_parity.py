@@ -251,10 +251,15 @@ def test_cast_transpose(ops, rows, cols):
     src = torch.randn(rows, cols, generator=torch.Generator().manual_seed(rows + cols)).to(DEV)
     dst = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
     dst_t = torch.empty(cols, rows, dtype=torch.bfloat16, device=DEV)
-    _lib.check(_lib.lib().star_cast_transpose_bf16(_lib.ptr(src), rows, cols, _lib.ptr(dst), _lib.ptr(dst_t),
+    _lib.check(_lib.lib().star_cast_transpose_bf16(_lib.ptr(src), rows, cols, _lib.ptr(dst), _lib.ptr(dst_t), None,
                                                    _lib.stream_ptr()), "star_cast_transpose_bf16")
     ref = src.to(torch.bfloat16)
     assert torch.equal(dst, ref) and torch.equal(dst_t, ref.t().contiguous())
+    # with a row scale on the transposed copy only (the backward's (diag(w2) W1)^T): one rounding of the product
+    sc = torch.randn(rows, generator=torch.Generator().manual_seed(rows)).to(DEV)
+    _lib.check(_lib.lib().star_cast_transpose_bf16(_lib.ptr(src), rows, cols, _lib.ptr(dst), _lib.ptr(dst_t),
+                                                   _lib.ptr(sc), _lib.stream_ptr()), "star_cast_transpose_bf16")
+    assert torch.equal(dst, ref) and torch.equal(dst_t, (src * sc[:, None]).to(torch.bfloat16).t().contiguous())
 
 
 @pytest.mark.parametrize("B,T,d", [(4, 250, 768), (2, 301, 1024), (1, 37, 128)])

@@ -333,3 +333,30 @@ def test_scorer_hint_does_not_leak_into_later_backward(ops):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         grads(torch.arange(N + 1, dtype=torch.int32, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------ forward variants
+@pytest.mark.parametrize("B,h,L,K,hd,ilk", [(4, 8, 128, 375, 128, False), (2, 4, 300, 750, 128, True),
+                                            (3, 2, 60, 63, 64, False), (2, 8, 227, 229, 128, True),
+                                            (1, 2, 16, 1000, 64, False)])
+def test_xattn_forward_ring_vs_register_staged(ops, B, h, L, K, hd, ilk):
+    """The LDS-DMA ring forward (default for hd 64 / 128) and the register-staged forward (hd 96; forced here through
+    star_test_override) against the oracle and against each other, with ragged key lengths and without a bias."""
+    q, k, v, sc, gout, klen = _drop_case(B, h, L, K, hd, 31 + K)
+    kmask = torch.from_numpy(lmask(klen, K))
+    key_len = torch.tensor(klen, dtype=torch.int32, device=DEV)
+    qd, kd, vd = (t.to(torch.bfloat16).to(DEV) for t in (q, k, v))
+    for use_bias in (True, False):
+        o_ref, p_ref = orc.xattn_core(bf16_round(q), bf16_round(k), bf16_round(v), kmask, sc if use_bias else None, ilk)
+        outs = []
+        try:
+            for mode in (0, 1):
+                ops.test_override(ops.OVR_XA_FWD, mode)
+                o, pw = ops.xattn(qd, kd, vd, bias=sc.to(DEV) if use_bias else None, key_len=key_len,
+                                  ilk_diag=2 if ilk else -1, need_probs=True)
+                close(o, o_ref, f"O mode {mode}")
+                close(pw, p_ref, f"P mode {mode}", 2e-3)       # P = exp(logit - lse): checks the LSE of either kernel
+                outs.append(o.float().cpu())
+        finally:
+            ops.test_override(ops.OVR_XA_FWD, 0)
+        close(outs[0], outs[1], "ring vs register-staged", 1e-2)

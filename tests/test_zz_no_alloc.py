@@ -15,12 +15,12 @@ def _scores(L, fn_static, x, w1b, b1, w2, b2):
     out = torch.full((N,), float("nan"), dtype=torch.float32, device=DEV)
     if fn_static:
         rc = L.star_scorer_fwd_static(x.data_ptr(), w1b.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), N, d,
-                                      out.data_ptr(), _lib.stream_ptr())
+                                      out.data_ptr(), None, _lib.stream_ptr())
     else:
         wsb = L.star_scorer_fwd_workspace(N, d)
         ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
         rc = L.star_scorer_fwd(x.data_ptr(), w1b.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), N, d,
-                               out.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr())
+                               out.data_ptr(), None, ws.data_ptr(), wsb, _lib.stream_ptr())
     _lib.check(rc, "star_scorer_fwd_static" if fn_static else "star_scorer_fwd")
     torch.cuda.synchronize()
     return out
@@ -47,5 +47,5 @@ def test_scorer_fwd_static_matches_workspace_variant():
     assert big > (4 << 20)
     x = torch.zeros(8, 1024, dtype=torch.bfloat16, device=DEV)
     rc = L.star_scorer_fwd_static(x.data_ptr(), x.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 600_000,
-                                  1024, x.data_ptr(), _lib.stream_ptr())
+                                  1024, x.data_ptr(), None, _lib.stream_ptr())
     assert rc == -3 and b"static array holds" in L.star_last_error()
