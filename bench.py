@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- valid encoder frames/s of one NuggetStep (scorer + select + gather + nl x score-biased
+"""bench.py -- valid encoder frames/s of one NuggetStep (scorer + select / fire scan + gather + nl x score-biased
 cross-attention, forward + backward) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                 # configs[1], the headline workload
+    python bench.py --config 2 | --config 3 | --rate 2|8|12        # the other BASELINE.json configurations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload at every N (weak scaling, per-GPU work fixed): BASELINE.json configs[1] -- wav2vec2-large-shaped
-states B=32, T=1500, d=1024, compress rate 4 (K=375), 4 decoder layers x 8 heads, L=128, bf16, synthetic.
-For N>1 every rank owns its own 32 utterances and the step ends with one flat RCCL all-reduce of the scorer
-gradients.  The step is captured once in a HIP graph (no host sync inside it) and replayed.
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+Workloads (weak scaling: per-GPU work is fixed, every rank owns its own utterances), all d = 1024, 4 decoder layers x
+8 heads, bf16, synthetic wav2vec2-shaped states:
+  --config 1  BASELINE.json configs[1]: non-streaming step, B = 32, T = 1500, compress rate 4 (K = 375), L = 128
+  --config 2  configs[2]: simultaneous step (CIF-regularised scorer, resize, fire scan), B = 64, MuST-C-shaped
+              log-normal lengths up to 1500 frames, L_b = 0.075 n_b + 2, ILK off
+  --config 3  configs[3]: simultaneous step with the infinite-lookback mask, B = 16, T = 3000, L = 227
+For N > 1 the step carries the gradient all-reduces of SURVEY.md section 8e over RCCL: the scorer's flat fp32
+gradient buffer (1.05 M values) and the decoder's cross-attention parameter gradients (nl x (4 d^2 + 6 d) = 16.8 M
+values; the decoder weights themselves are outside the hot path, so that buffer is payload of the right size).  The
+second buffer is reduced on a side stream as soon as the attention backward kernels are done, beside the gather and
+scorer backward.  The step is captured in two HIP graphs (no host sync inside) and replayed.
+Prints ONE JSON line on rank 0 (fields: DESIGN.md section 5).
 """
 import argparse
 import json
@@ -22,9 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0            # HBM3E (same table; a streaming copy reaches about 6.3 TB/s of it)
 
 
 def parse():
@@ -32,26 +42,50 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3), help="BASELINE.json configs[i]")
     ap.add_argument("--rate", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--tgt", type=int, default=128)
+    ap.add_argument("--tgt", type=int, default=None)
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-all", action="store_true", help="skip the per-kernel-class roofline legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--breakdown", action="store_true", help="also print per-stage HIP-event timings to stderr")
     return ap.parse_args()
 
 
-def cpu_baseline(args, seconds):
+def workload(args, rank):
+    """Lengths / target lengths / shapes of the chosen BASELINE.json configuration (seeded per rank)."""
+    if args.config == 1:
+        B, T, L = args.batch or 32, args.frames or 1500, args.tgt or 128
+        return dict(kind="asr", B=B, T=T, L=L, lengths=[T] * B, targets=None, ilk=False,
+                    name="configs[1]: non-streaming nugget compression, wav2vec2-large states"
+                    + ("" if args.rate == 4 else f", compress rate {args.rate}"))
+    if args.config == 2:
+        B, T = args.batch or 64, args.frames or 1500
+        rng = np.random.default_rng(4321 + rank)
+        # MuST-C-shaped durations (SURVEY.md 8d): n_b = clip(round(50 * LogNormal(ln 6.0, 0.6)), 50, 1500) frames
+        n = np.clip(np.round(50.0 * rng.lognormal(np.log(6.0), 0.6, size=B)), 50, T).astype(int)
+        n[0] = T                               # the padded batch is T frames long
+        tl = np.clip(np.round(0.075 * n) + 2, 4, 512).astype(int)
+        return dict(kind="simul", B=B, T=T, L=int(tl.max()), lengths=[int(v) for v in n], targets=[int(v) for v in tl],
+                    ilk=False,
+                    name="configs[2]: simul_s2t path, CIF-regularised scorer + fire scan, MuST-C-shaped lengths")
+    B, T, L = args.batch or 16, args.frames or 3000, args.tgt or 227
+    return dict(kind="simul", B=B, T=T, L=L, lengths=[T] * B, targets=[L] * B, ilk=True,
+                name="configs[3]: simultaneous S2T with --use_ilk, long-form utterances")
+
+
+def cpu_baseline(args, wl, seconds):
     """The CPU oracle (port of the reference path, fp32, torch CPU threads) on a bounded sample of the SAME
-    workload: 2 utterances of T frames per step, same d / rate / layers / L."""
+    workload: 2 utterances of T frames per step, same d / rate / layers / L (non-streaming NuggetStep)."""
     from oracle import nugget_oracle as orc
     torch.manual_seed(0)
-    B, T, d, h, L, nl = 2, args.frames, args.dim, args.heads, args.tgt, args.layers
+    B, T, d, h, L, nl = 2, wl["T"], args.dim, args.heads, wl["L"], args.layers
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(99)
     x = torch.randn(B, T, d, generator=g).requires_grad_()
@@ -87,17 +121,49 @@ def cpu_baseline(args, seconds):
 
 def pmc_traffic(N, d):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
-    as the gfx950 note prescribes + WRITE_SIZE; profiles/r01_v42_pmc_scorer_fwd.json).  PMC passes cannot run
+    as the gfx950 note prescribes + WRITE_SIZE; profiles/r0*_pmc_scorer_fwd.json).  PMC passes cannot run
     inside this process, so the figure is only reported for the exact workload it was collected on; else None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v42_pmc_scorer_fwd.json")
-    try:
-        with open(path) as f:
-            doc = json.load(f)
-        if doc.get("algorithmic_bytes_per_launch") == N * d * 2 + d * d * 2 + N * 4:
-            return round(float(doc["traffic_bytes_per_launch"]))
-    except (OSError, ValueError, KeyError):
-        pass
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_scorer_fwd.json", "r01_v42_pmc_scorer_fwd.json"):
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                doc = json.load(f)
+            if doc.get("algorithmic_bytes_per_launch") == N * d * 2 + d * d * 2 + N * 4:
+                return round(float(doc["traffic_bytes_per_launch"]))
+        except (OSError, ValueError, KeyError):
+            continue
     return None
+
+
+def event_time_us(fn, iters=10, warm=3, graph=True):
+    """Average device time of fn() in microseconds, HIP events on the stream the kernels are launched on.
+    graph=True: `iters` launches captured in one HIP graph and replayed between one pair of events (no host launch
+    gaps: right for legs of a few microseconds); graph=False: one pair of events around every eager launch (a kernel of
+    ~100 us, long enough to hide the launch gap, as it runs inside the step with other kernels between repeats)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    if not graph:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / iters * 1e3
+    g = torch.cuda.CUDAGraph()
+    # capture on the CURRENT stream: autograd runs a backward node on the stream its forward ran on, so a leg whose
+    # forward was built outside the capture must be captured on that same stream
+    with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
 
 
 def main():
@@ -118,20 +184,31 @@ def main():
 
     from star_amd import _lib, ops
     from star_amd.nugget import NuggetScorer
-    from star_amd.step import make_inputs, nugget_step_asr
+    from star_amd.step import attention_backward, backward_rest, make_inputs, nugget_step_asr, nugget_step_simul
 
-    B, T, d, h, L, nl, rate = args.batch, args.frames, args.dim, args.heads, args.tgt, args.layers, args.rate
-    lengths = [T] * B
+    wl = workload(args, rank)
+    B, T, L, d, h, nl, rate = wl["B"], wl["T"], wl["L"], args.dim, args.heads, args.layers, args.rate
+    lengths = wl["lengths"]
+    simul = wl["kind"] == "simul"
     torch.manual_seed(1234)                      # identical scorer replicas on every rank
     scorer = NuggetScorer(d).to(dev)
-    inp = make_inputs(lengths, T, d, h, L, nl, dev, seed=1234 + rank)
+    if simul:
+        with torch.no_grad():
+            scorer[2].bias.fill_(-2.5)           # sigmoid(score) ~ 0.08: sum of alphas in the range of the target lengths
+    inp = make_inputs(lengths, T, d, h, L, nl, dev, seed=1234 + rank, target_lengths=wl["targets"])
     params = list(scorer.parameters())
-    grad_targets = params + [inp.x, inp.s] + inp.qs
+    act_targets = ([] if simul else [inp.x]) + [inp.s] + inp.qs     # the simultaneous scorer sees X detached
+    grad_targets = params + act_targets
     allreduce = sd.FlatGradAllReduce(params)
+    decoder_side = None
     if world > 1:
         # the scorer gradients live in the flat all-reduce buffer: no copies around the collective
         allreduce.attach()
-        grad_targets = [inp.x, inp.s] + inp.qs
+        grad_targets = act_targets
+        # decoder cross-attention parameter gradients per layer: c_attn d x 2d, q_attn d x d, c_proj d x d, their
+        # biases (4d) and ln_cross_attn (2d).  The weights are outside the hot path; their
+        # all-reduce is part of the step, so the buffer has the real size.
+        decoder_side = sd.SideStreamAllReduce(torch.zeros(nl * (4 * d * d + 6 * d), dtype=torch.float32, device=dev))
 
     def reset_grads():
         for t in grad_targets:
@@ -139,9 +216,23 @@ def main():
         if world > 1:
             allreduce.zero()
 
-    def step():
+    def forward():
+        if simul:
+            return nugget_step_simul(scorer, inp, use_ilk=wl["ilk"], backward=False)
+        return nugget_step_asr(scorer, inp, rate, backward=False)
+
+    def rest(out, dmem, dsg):
+        if simul:
+            ql = out["quantity_loss"]
+            backward_rest(out, dmem, dsg, [ql], [torch.full_like(ql, 0.01)])
+        else:
+            backward_rest(out, dmem, dsg)
+
+    def step():                                  # eager
         reset_grads()
-        nugget_step_asr(scorer, inp, rate)
+        out = forward()
+        dmem, dsg = attention_backward(out, inp)
+        rest(out, dmem, dsg)
 
     # ---- eager warm-up (also fills the per-rate caches and the allocator), then graph capture
     side = torch.cuda.Stream()
@@ -151,22 +242,37 @@ def main():
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = None
+    graph_a = graph_b = None
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
+        # two graphs: forward + attention backward | gather / scorer backward.  For N > 1 the decoder-side
+        # all-reduce starts between them; at N = 1 they replay back to back.
         reset_grads()
-        with torch.cuda.graph(graph):
+        graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_a):
             if world > 1:
                 allreduce.zero()               # part of the replayed step: backward accumulates into the buffer
-            nugget_step_asr(scorer, inp, rate)
+            out_c = forward()
+            dmem_c, dsg_c = attention_backward(out_c, inp)
+        graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+            rest(out_c, dmem_c, dsg_c)
 
-    def run_step():
-        if graph is not None:
-            graph.replay()
+    def run_step(with_allreduce=True):
+        if graph_a is not None:
+            graph_a.replay()
         else:
-            step()
-        if world > 1:
+            reset_grads()
+            out = forward()
+            dmem, dsg = attention_backward(out, inp)
+        if world > 1 and with_allreduce:
+            decoder_side.start(world)            # side stream: runs beside the gather / scorer backward
+        if graph_b is not None:
+            graph_b.replay()
+        else:
+            rest(out, dmem, dsg)
+        if world > 1 and with_allreduce:
             allreduce(world)
+            decoder_side.join()
 
     for _ in range(args.warmup):
         run_step()
@@ -179,28 +285,26 @@ def main():
     sd.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sd.max_over_ranks(elapsed, dev)
-    frames_per_step = float(sum(lengths)) * world
+    frames_local = float(sum(lengths))
+    frames_per_step = sd.sum_over_ranks(frames_local, dev)
     ms_per_step = elapsed / args.steps * 1e3
 
-    # for N > 1 also report the step without its gradient all-reduce (same K steps, same
-    # barrier / max-over-ranks bracket); `value` and `ms_per_step` above always include the all-reduce.
+    # for N > 1 also report the step without its gradient all-reduces (same K steps, same
+    # barrier / max-over-ranks bracket); `value` and `ms_per_step` above always include them.
     compute_ms = None
     if world > 1:
         sd.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            if graph is not None:
-                graph.replay()
-            else:
-                step()
+            run_step(with_allreduce=False)
         torch.cuda.synchronize()
         sd.barrier()
         compute_ms = sd.max_over_ranks(time.perf_counter() - t1, dev) / args.steps * 1e3
 
     # ---- roofline of the dominant kernel: the fused scorer GEMM (gemm_nt_kernel<EPI_SCORE>), timed with
     # HIP events on the stream it is launched on.  Algorithmic FLOP per launch = N_f * (2 d^2 + 2 d).
-    roofline = None
+    roofline = roofline_all = None
     if rank == 0:
         N = B * T
         xb = inp.x.detach().view(N, d)
@@ -217,30 +321,31 @@ def main():
             _lib.check(_lib.lib().star_scorer_fwd(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
                                                   b2f.data_ptr(), N, d, sc.data_ptr(), bits.data_ptr(), ws.data_ptr(),
                                                   wsb, _lib.stream_ptr()), "star_scorer_fwd")
-        for _ in range(3):
-            launch()
-        iters = max(args.steps, 10)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for a, b in evs:
-            a.record()
-            launch()
-            b.record()
-        torch.cuda.synchronize()
-        avg_ms = sum(a.elapsed_time(b) for a, b in evs) / iters
+        legs_stream = torch.cuda.Stream()         # graph capture needs a non-default stream
+        legs_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(legs_stream)
+        avg_us = event_time_us(launch, iters=max(args.steps, 10), graph=False)
         flops = float(N) * (2.0 * d * d + 2.0 * d)
-        ach = flops / (avg_ms * 1e-3) / 1e12
+        ach = flops / (avg_us * 1e-6) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_SCORE> (+ scorer_finish_kernel)", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(N, d), "avg_us": round(avg_ms * 1e3, 2), "flop_per_launch": flops}
+                    "traffic": pmc_traffic(N, d), "avg_us": round(avg_us, 2), "flop_per_launch": flops}
+        if not args.no_roofline_all:
+            roofline_all = roofline_legs(ops, scorer, inp, wl, rate, dev, roofline)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
 
-    if args.breakdown and rank == 0:
+    if args.breakdown and rank == 0 and not simul:
         breakdown(scorer, inp, rate, dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, args.cpu_seconds)
+        cpu = cpu_baseline(args, wl, args.cpu_seconds)
 
     if rank == 0:
+        headline = args.config != 1 or (B, T, d, h, L, nl) == (32, 1500, 1024, 8, 128, 4)
+        headline = headline and args.batch is None and args.frames is None and args.tgt is None
+        n_dec = decoder_side.flat.numel() if decoder_side is not None else 0
         rec = {
             "metric": "encoder frames/sec, nugget scorer+select+cross-attn fwd+bwd",
             "value": frames_per_step / (elapsed / args.steps),
@@ -254,21 +359,112 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]: non-streaming nugget compression, wav2vec2-large states"
-                                    if (B, T, d, h, L, nl, rate) == (32, 1500, 1024, 8, 128, 4, 4)
-                                    else "custom shape (parity-case configuration, not the headline workload)"),
-                       "batch_per_gpu": B, "global_batch": B * world, "frames": T, "d": d, "rate": rate,
-                       "K": int(inp.key_len_dev(rate)[1]), "layers": nl, "heads": h, "tgt_len": L,
-                       "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "grad_allreduce": "flat fp32 scorer grads, 1 per step" if world > 1 else None,
+            "config": {"workload": wl["name"] if headline else
+                       "custom shape (parity-case configuration, not a BASELINE.json workload)",
+                       "step": ("simultaneous (quantity loss, resize, fire scan, ILK %s)" % ("on" if wl["ilk"] else "off"))
+                       if simul else "non-streaming (top-k select)",
+                       "batch_per_gpu": B, "global_batch": B * world, "frames": T,
+                       "valid_frames_per_gpu": int(frames_local), "d": d, "rate": None if simul else rate,
+                       "K": int(L + 2) if simul else int(inp.key_len_dev(rate)[1]), "layers": nl, "heads": h, "tgt_len": L,
+                       "parallelism": f"dp{world}", "hip_graph": graph_a is not None,
+                       "loss_scalar": "not formed in the timed step: the cotangents G_l of loss = sum_l <O_l, G_l> are fed "
+                                      "to backward directly (one reduction kernel per layer left out; tests form the scalar)",
+                       "grad_allreduce": ("2 flat fp32 buffers per step: scorer (%d values) after the step; decoder "
+                                          "cross-attention parameters (%d values) on a side stream after the attention "
+                                          "backward" % (allreduce.flat.numel(), n_dec)) if world > 1 else None,
+                       "allreduce_bytes": 4 * (allreduce.flat.numel() + n_dec) if world > 1 else None,
                        "compute_only_ms_per_step": compute_ms,
+                       "with_allreduce_ms_per_step": ms_per_step if world > 1 else None,
                        "allreduce_ms_per_step": None if compute_ms is None else max(ms_per_step - compute_ms, 0.0)},
             "roofline": roofline,
+            "roofline_all": roofline_all,
             "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg):
+    """One entry per kernel class of the path (north_star: MFMA utilisation for the scorer and the attention core,
+    HBM GB/s for select / gather / scan).  Every leg is a stand-alone launch timed with HIP events on the launch
+    stream, so operands can be L2 / Infinity-Cache warm between repeats (the in-step kernel times are in
+    profiles/*_kernel_stats.csv); achieved = ALGORITHMIC flops or bytes / time."""
+    B, T, d = inp.x.shape
+    h, L = inp.qs[0].shape[1], inp.qs[0].shape[2]
+    legs = [dict(scorer_leg, name="scorer forward GEMM")]
+    simul = wl["kind"] == "simul"
+
+    def leg(name, kernel, us, flops=None, bytes_=None):
+        e = {"name": name, "kernel": kernel, "avg_us": round(us, 2)}
+        if flops is not None:
+            tf = flops / (us * 1e-6) / 1e12
+            e.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                     frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flops)
+            gb = bytes_ / (us * 1e-6) / 1e9
+            e.update(hbm_gbs=round(gb, 1), hbm_frac=round(gb / HBM_PEAK_GBS, 4), bytes_per_launch=bytes_)
+        else:
+            gb = bytes_ / (us * 1e-6) / 1e9
+            e.update(bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gb / HBM_PEAK_GBS, 4),
+                     bytes_per_launch=bytes_)
+        legs.append(e)
+
+    with torch.no_grad():
+        scores = scorer(inp.x).squeeze(-1).float()
+    if simul:
+        alphas, _ = ops.cif_quantity(scores, inp.target_lengths_dev, lengths=inp.lengths_dev)
+        resized = ops.cif_resize(alphas, inp.target_lengths_dev)
+        cap = int(max(inp.target_lengths)) + 2
+        us = event_time_us(lambda: ops.cif_quantity(scores, inp.target_lengths_dev, lengths=inp.lengths_dev))
+        leg("quantity (sigmoid, masked sum, L1 loss)", "cif_quantity_kernel", us, bytes_=8.0 * B * T)
+        us = event_time_us(lambda: ops.cif_resize(alphas, inp.target_lengths_dev))
+        leg("resize", "cif_resize_kernel", us, bytes_=8.0 * B * T)
+        us = event_time_us(lambda: ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap))
+        leg("fire scan", "cif_fire_scan_kernel", us, bytes_=4.0 * B * T + 9.0 * B * cap)
+        idx, nmask, counts, _, _ = ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap)
+        key_len, K = counts, cap
+        ilk = 2 if wl["ilk"] else -1
+        kb = counts.cpu().numpy().astype(np.float64)
+        lq = np.minimum(np.asarray(inp.target_lengths, dtype=np.float64), L)
+    else:
+        key_len, K = inp.key_len_dev(rate)
+        us = event_time_us(lambda: ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K))
+        leg("top-k select + type table", "topk_select_kernel", us, bytes_=4.0 * B * T + 8.0 * B * T + 21.0 * B * K)
+        _, idx, _, _, _ = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K)
+        ilk = -1
+        kb = np.asarray(ops.nugget_counts_host(inp.lengths, rate), dtype=np.float64)
+        lq = np.full(B, float(L))
+    sg = ops.gather_rows(scores, idx)
+    s_det = inp.s.detach()
+    us = event_time_us(lambda: ops.gather_rows(s_det, idx))
+    leg("row gather forward", "gather_rows_fwd_kernel", us, bytes_=2.0 * 2 * d * B * K)
+    sreq = s_det.clone().requires_grad_()
+    mem = ops.gather_rows(sreq, idx)
+    gm = torch.randn_like(mem)
+    us = event_time_us(lambda: torch.autograd.grad(mem, sreq, gm, retain_graph=True))
+    leg("row gather backward (every dS row written once)", "gather_rows_bwd_kernel", us,
+        bytes_=2.0 * d * B * K + 2.0 * d * B * T)
+    # attention core, one layer: all B x L x K pairs are computed for the ILK-off core, the lower band for ILK
+    memd = mem.detach()
+    k = memd.view(B, K, h, d // h).permute(0, 2, 1, 3)
+    q = inp.qs[0].detach()
+    if ilk < 0:
+        pairs = float((lq * kb).sum())
+    else:
+        pairs = float(sum(min(i + ilk + 1, kk) for l_, kk in zip(lq, kb) for i in range(int(l_))))
+    fwd_flops = 4.0 * pairs * d
+    fwd_bytes = 2.0 * d * (2 * B * L + 2 * B * K)
+    us = event_time_us(lambda: ops.xattn(q, k, k, bias=sg, key_len=key_len, ilk_diag=ilk))
+    leg("attention core forward (1 layer)", "xattn_fwd_ring_kernel", us, flops=fwd_flops, bytes_=fwd_bytes)
+    qg, kg, vg = q.clone().requires_grad_(), k.clone().requires_grad_(), k.clone().requires_grad_()
+    sgg = sg.detach().clone().requires_grad_()
+    o, _ = ops.xattn(qg, kg, vg, bias=sgg, key_len=key_len, ilk_diag=ilk)
+    go = torch.randn(B, L, h, d // h, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
+    us = event_time_us(lambda: torch.autograd.grad(o, (qg, kg, vg, sgg), go, retain_graph=True))
+    leg("attention core backward (1 layer, with the bias-gradient reduction)",
+        "xattn_bwd_fused_small_kernel | xattn_bwd_dq_ring_kernel + xattn_bwd_dkv_*", us,
+        flops=2.5 * fwd_flops, bytes_=2.0 * d * (4 * B * L + 4 * B * K))
+    return legs
 
 
 def breakdown(scorer, inp, rate, dev):

@@ -385,3 +385,39 @@ def nugget_step_asr(x, s_repr, lengths, rate, w1, b1, w2, b2, qs, kv_scales, gs)
         loss = loss + (o * g).sum()
     return {"scores": scores, "indices": idx, "mask": nmask, "table": table, "positions": pos,
             "scores_gather": sg, "mem": mem, "loss": loss}
+
+
+def nugget_step_simul(x, s_repr, lengths, target_lengths, use_ilk, w1, b1, w2, b2, qs, kv_scales, gs,
+                      fires=None):
+    """One NuggetStep of the simultaneous path (w2v_simul.py:407-461), fp32 on CPU: scorer on the detached encoder
+    states (:410-411), alphas and quantity loss (:419-423), resize (:425), fire scan on the detached resized alphas
+    (:426), score gather (:427), type table (:431), row gather (:446-447), nl x score-biased cross-attention (ILK mask
+    j <= i + 2 when use_ilk), loss = sum_l <O_l, G_l> + 0.01 * quantity (:461).
+
+    fires = (nugget_mask, nugget_indices) replaces the oracle's own fire positions (a test passes the kernel's, which
+    it has checked separately, so that a one-ulp score difference cannot move a fire and hide everything after it)."""
+    bsz, t, d = x.shape
+    h = qs[0].shape[1]
+    mask = torch.arange(t)[None, :] < torch.tensor(lengths)[:, None]
+    tl = torch.as_tensor(target_lengths)
+    scores = scorer(x.detach(), w1, b1, w2, b2)
+    alphas, qloss = quantity_loss(scores, mask, tl)
+    resized = resize(alphas, tl)
+    if fires is None:
+        nmask, idx, _ = fire_scan(resized.numpy(), mask.numpy(), with_block_mask=False)
+    else:
+        nmask, idx = (np.asarray(v) for v in fires)
+    idx_t = torch.from_numpy(idx.astype(np.int64))
+    nmask_t = torch.from_numpy(nmask.astype(bool))
+    sg = gather_rows(scores.unsqueeze(-1), idx_t).squeeze(-1)
+    table, pos = type_table(t, idx, nmask)
+    mem = gather_rows(s_repr, idx_t)
+    loss = x.new_zeros(())
+    for q, (ak, av), g in zip(qs, kv_scales, gs):
+        kk = (mem * ak).view(bsz, -1, h, d // h).transpose(1, 2)
+        vv = (mem * av).view(bsz, -1, h, d // h).transpose(1, 2)
+        o, _ = xattn_core(q, kk, vv, nmask_t, sg, bool(use_ilk))
+        loss = loss + (o * g).sum()
+    return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
+            "mask": nmask, "table": table, "positions": pos, "scores_gather": sg, "mem": mem,
+            "loss": loss + 0.01 * qloss}

@@ -107,7 +107,7 @@ def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward
     if backward:
         torch.autograd.backward(outs, inp.gs)
     return {"scores": scores, "nugget_mask": nmask, "indices": idx, "scores_gather": sg, "type_table": table,
-            "positions": pos, "mem": mem, "loss": loss}
+            "positions": pos, "mem": mem, "loss": loss, "outs": outs}
 
 
 def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, backward: bool = True,
@@ -131,4 +131,21 @@ def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, back
         torch.autograd.backward(outs + [qloss], inp.gs + [torch.full_like(qloss, 0.01)])
     return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
             "nugget_mask": nmask, "counts": counts, "max_count": mx, "scores_gather": nugget_scores,
-            "type_table": table, "positions": pos, "mem": mem, "loss": total}
+            "type_table": table, "positions": pos, "mem": mem, "loss": total, "outs": outs}
+
+
+def attention_backward(out, inp: StepInputs):
+    """First half of a two-stage backward (multi-GPU step): the nl attention backward kernels and the shared
+    bias-gradient reduction only.  Returns (d mem, d scores_gather); the decoder-side gradients are complete after
+    this stage, so their all-reduce can start while backward_rest() runs."""
+    grads = torch.autograd.grad(out["outs"], [out["mem"], out["scores_gather"]] + list(inp.qs), inp.gs)
+    return grads[0], grads[1]
+
+
+def backward_rest(out, dmem, dsg, extra=None, extra_grads=None):
+    """Second half: row-gather backward, score scatter and the scorer backward (plus the quantity loss in the
+    simultaneous step, passed as extra / extra_grads)."""
+    roots, gr = [out["mem"], out["scores_gather"]], [dmem, dsg]
+    if extra is not None:
+        roots, gr = roots + list(extra), gr + list(extra_grads)
+    torch.autograd.backward(roots, gr)

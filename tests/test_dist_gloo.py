@@ -1,5 +1,6 @@
-"""world_size-2 gloo test of the N>1 path: sharded utterances + one flat gradient all-reduce give the
-single-process gradients (utterances are independent, so this is exact up to summation order)."""
+"""world_size-2 gloo tests of the N>1 path: sharded utterances + the flat gradient all-reduces give the
+single-process gradients (utterances are independent, so this is exact up to summation order).  The second test
+covers bench.py's two-buffer step: a two-stage backward with the decoder-side buffer reduced between the stages."""
 import os
 import sys
 
@@ -64,6 +65,69 @@ def test_sharded_allreduce_matches_single_process(tmp_path, attach):
     for g, p in zip(got, full):
         # DDP semantics: mean over ranks of per-rank sums == full-batch sum / world
         np.testing.assert_allclose(g.numpy(), (p.grad / 2).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _two_stage_loss(x, lengths, rate, params, dec):
+    """Stand-in for the step with a decoder side: selected scores -> (scores * dec) 'attention' -> loss.  Returns
+    (loss, sg): sg is the boundary between the two backward stages, like scores_gather in star_amd.step."""
+    from oracle import nugget_oracle as orc
+    w1, b1, w2, b2 = params
+    t = x.shape[1]
+    mask = np.arange(t)[None, :] < np.asarray(lengths)[:, None]
+    s = orc.scorer(x, w1, b1, w2, b2)
+    nmask, idx, _ = orc.topk_select(s.detach().numpy(), mask, rate)
+    sg = s.gather(1, torch.from_numpy(idx)) * torch.from_numpy(nmask)
+    out = torch.tanh(sg.unsqueeze(-1) * dec.unsqueeze(0).unsqueeze(0))        # [b, k, m]
+    return (out ** 2).sum(), sg
+
+
+def _worker2(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from star_amd import dist as sd
+    sd.init(backend="gloo")
+    data = torch.load(os.path.join(tmp, "data.pt"))
+    mine = sd.shard(list(range(len(data["lengths"]))), rank, world)
+    params = [torch.nn.Parameter(p.clone()) for p in data["params"]]
+    dec = torch.nn.Parameter(data["dec"].clone())
+    ar = sd.FlatGradAllReduce(params).attach()
+    ar.zero()
+    dec_flat = torch.zeros(dec.numel())
+    side = sd.SideStreamAllReduce(dec_flat)
+    loss, sg = _two_stage_loss(data["x"][mine], [data["lengths"][i] for i in mine], 4, params, dec)
+    # stage 1: "attention backward": decoder-side gradients + the cotangent of the boundary
+    dsg, ddec = torch.autograd.grad(loss, [sg, dec])
+    dec_flat.copy_(ddec.reshape(-1))
+    side.start(world)                              # reduced while stage 2 runs (in order on the host under gloo)
+    torch.autograd.backward([sg], [dsg])           # stage 2: scorer backward into the attached flat buffer
+    ar(world)
+    side.join()
+    frames = sd.sum_over_ranks(float(sum(data["lengths"][i] for i in mine)), "cpu")
+    assert frames == float(sum(data["lengths"]))
+    sd.barrier()
+    if rank == 0:
+        torch.save({"params": [p.grad for p in params], "dec": dec_flat}, os.path.join(tmp, "grads.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_buffer_two_stage_backward_matches_single_process(tmp_path):
+    torch.manual_seed(1)
+    d, t, b, m = 16, 40, 5, 7
+    lengths = [40, 12, 29, 40, 9]
+    x = torch.randn(b, t, d)
+    params = [torch.randn(d, d) * 0.2, torch.randn(d) * 0.1, torch.randn(1, d) * 0.2, torch.randn(1) * 0.1]
+    dec = torch.randn(m) * 0.5
+    torch.save({"x": x, "lengths": lengths, "params": params, "dec": dec}, tmp_path / "data.pt")
+    port = 30311 + os.getpid() % 200
+    mp.spawn(_worker2, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "grads.pt")
+    full = [torch.nn.Parameter(p.clone()) for p in params]
+    fdec = torch.nn.Parameter(dec.clone())
+    _two_stage_loss(x, lengths, 4, full, fdec)[0].backward()
+    for g, p in zip(got["params"], full):
+        np.testing.assert_allclose(g.numpy(), (p.grad / 2).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["dec"].numpy(), (fdec.grad / 2).numpy(), rtol=1e-5, atol=1e-6)
 
 
 def test_shard_partitions_everything():

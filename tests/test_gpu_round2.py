@@ -360,3 +360,204 @@ def test_xattn_forward_ring_vs_register_staged(ops, B, h, L, K, hd, ilk):
         finally:
             ops.test_override(ops.OVR_XA_FWD, 0)
         close(outs[0], outs[1], "ring vs register-staged", 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ whole simul step
+@pytest.mark.parametrize("ilk", [False, True])
+def test_nugget_step_simul_gradients_vs_oracle(ops, ilk):
+    """The simultaneous NuggetStep against the fp32 oracle step (w2v_simul.py:407-461): scores, alphas, quantity loss,
+    resized alphas, fire positions (bit-exact on the kernel's own resized alphas), loss, and every gradient of the
+    step -- scorer parameters (quantity loss + attention bias through the score gather), S, Q."""
+    from star_amd.nugget import NuggetScorer
+    from star_amd.step import make_inputs, nugget_step_simul
+    torch.manual_seed(1)
+    lengths, T, d, h, nl = [300, 280, 150, 60], 300, 256, 2, 2
+    tl = [int(round(0.075 * n)) + 2 for n in lengths]
+    L = max(tl)
+    scorer = NuggetScorer(d).to(DEV)
+    with torch.no_grad():
+        scorer[2].bias.fill_(-2.0)
+    inp = make_inputs(lengths, T, d, h, L, nl, DEV, target_lengths=tl)
+    out = nugget_step_simul(scorer, inp, use_ilk=ilk, with_loss=True)
+    mask = lmask(lengths, T)
+    o_mask, o_idx, _ = orc.fire_scan(out["resized"].cpu().numpy(), mask, with_block_mask=False)
+    kf = o_idx.shape[1]
+    np.testing.assert_array_equal(out["indices"][:, :kf].cpu().numpy(), o_idx)
+    assert (out["indices"][:, kf:] == -1).all()
+    np.testing.assert_array_equal(out["counts"].cpu().numpy(), o_mask.sum(1))
+
+    cpu = lambda t: t.detach().float().cpu()
+    w1, b1, w2, b2 = (cpu(p).requires_grad_() for p in (scorer[0].weight, scorer[0].bias, scorer[2].weight, scorer[2].bias))
+    w1r = bf16_round(w1.detach()).requires_grad_()
+    xr, sr = cpu(inp.x).requires_grad_(), cpu(inp.s).requires_grad_()
+    qs = [cpu(q).requires_grad_() for q in inp.qs]
+    K = out["indices"].shape[1]
+    fires = (out["nugget_mask"].cpu().numpy().astype(bool), out["indices"].cpu().numpy())
+    ref = orc.nugget_step_simul(xr, sr, lengths, tl, ilk, w1r, b1, w2, b2, qs, [(cpu(a), cpu(b)) for a, b in inp.kv_scales],
+                                [cpu(g) for g in inp.gs], fires=fires)
+    assert fires[1].shape[1] == K
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), ref["scores"].detach().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out["alphas"].detach().cpu().numpy(), ref["alphas"].detach().numpy(), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(out["resized"].detach().cpu().numpy(), ref["resized"].detach().numpy(), rtol=2e-3, atol=1e-4)
+    assert abs(out["quantity_loss"].item() - ref["quantity_loss"].item()) <= 5e-3 * abs(ref["quantity_loss"].item()) + 1e-4
+    ref["loss"].backward()
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-2 * abs(ref["loss"].item()) + 1e-2
+    close(scorer[0].weight.grad, w1r.grad, "dW1", 3e-2)
+    close(scorer[2].weight.grad, w2.grad, "dw2", 3e-2)
+    close(scorer[0].bias.grad, b1.grad, "db1", 3e-2)
+    close(scorer[2].bias.grad, b2.grad, "db2", 3e-2)
+    close(inp.s.grad, sr.grad, "dS", 3e-2)
+    for l in range(nl):
+        close(inp.qs[l].grad, qs[l].grad, f"dQ{l}", 3e-2)
+    assert inp.x.grad is None and xr.grad is None          # w2v_simul.py:410: the scorer sees detached states
+
+
+def test_two_stage_backward_equals_single_backward(ops):
+    """bench.py's multi-GPU step splits the backward after the attention kernels (star_amd.step.attention_backward /
+    backward_rest).  Same kernels in the same order on the same operands: bit-identical gradients."""
+    from star_amd.nugget import NuggetScorer
+    from star_amd.step import attention_backward, backward_rest, make_inputs, nugget_step_asr, nugget_step_simul
+    torch.manual_seed(2)
+    lengths, T, d, h, nl = [200, 180, 77], 200, 256, 4, 2
+    tl = [int(round(0.075 * n)) + 2 for n in lengths]
+    scorer = NuggetScorer(d).to(DEV)
+    inp = make_inputs(lengths, T, d, h, max(tl), nl, DEV, target_lengths=tl)
+    leaves = list(scorer.parameters()) + [inp.x, inp.s] + inp.qs
+
+    def grads():
+        g = [None if t.grad is None else t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        return g
+
+    for simul in (False, True):
+        if simul:
+            nugget_step_simul(scorer, inp, use_ilk=True)
+        else:
+            nugget_step_asr(scorer, inp, 4)
+        one = grads()
+        out = nugget_step_simul(scorer, inp, use_ilk=True, backward=False) if simul else \
+            nugget_step_asr(scorer, inp, 4, backward=False)
+        dmem, dsg = attention_backward(out, inp)
+        if simul:
+            ql = out["quantity_loss"]
+            backward_rest(out, dmem, dsg, [ql], [torch.full_like(ql, 0.01)])
+        else:
+            backward_rest(out, dmem, dsg)
+        two = grads()
+        nq = len(leaves) - len(inp.qs)
+        for i, (a, b) in enumerate(zip(one, two)):
+            if i >= nq:
+                assert b is None                        # autograd.grad returns dQ instead of accumulating it
+                continue
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
+
+
+def _simul_full_size(ops, B, T, lengths, tl, use_ilk, seed):
+    """A whole simultaneous step at a BASELINE.json size, checked through size-independent properties."""
+    from star_amd.nugget import NuggetScorer
+    from star_amd.step import make_inputs, nugget_step_simul
+    torch.manual_seed(seed)
+    d, h, nl = 1024, 8, 4
+    L = max(tl)
+    scorer = NuggetScorer(d).to(DEV)
+    with torch.no_grad():
+        scorer[2].bias.fill_(-2.5)
+    inp = make_inputs(lengths, T, d, h, L, nl, DEV, seed=seed, target_lengths=tl)
+    out = nugget_step_simul(scorer, inp, use_ilk=use_ilk, with_loss=True)
+    n = np.asarray(lengths)
+    t_np = np.asarray(tl)
+    mask = lmask(lengths, T)
+    al, rs = out["alphas"].detach().cpu().numpy(), out["resized"].detach().cpu().numpy()
+    assert (al[~mask] == 0).all() and (rs[~mask] == 0).all()
+    # resize: row sums equal the target lengths (rescale and fix-ups both keep the sum), every weight below 1
+    np.testing.assert_allclose(rs.sum(1, dtype=np.float64), t_np, rtol=2e-5)
+    assert rs.max() <= 1.0
+    ql = ((al.sum(1, dtype=np.float64) - t_np) ** 2).mean()
+    assert abs(out["quantity_loss"].item() - ql) <= 1e-4 * ql + 1e-5
+    # fire scan: ascending, inside the utterance, last valid frame always fires, count in {L_b, L_b + 1}
+    idx, cnt = out["indices"].cpu().numpy(), out["counts"].cpu().numpy()
+    assert idx.shape[1] == L + 2 and int(out["max_count"].item()) == cnt.max()
+    for b in range(B):
+        f = idx[b, :cnt[b]]
+        assert (np.diff(f) > 0).all() and f[0] >= 0 and f[-1] == n[b] - 1 and (idx[b, cnt[b]:] == -1).all()
+        assert t_np[b] - 1 <= cnt[b] <= t_np[b] + 1
+    # three rows of the scan bit-exact against the oracle on the kernel's own resized alphas
+    sub = [0, B // 2, B - 1]
+    o_mask, o_idx, _ = orc.fire_scan(rs[sub], mask[sub], with_block_mask=False)
+    for r, b in enumerate(sub):
+        np.testing.assert_array_equal(idx[b, :cnt[b]], o_idx[r, :o_mask[r].sum()])
+    # type table / positions / gathers are exact copies
+    tab = out["type_table"].cpu().numpy()
+    np.testing.assert_array_equal(tab.sum(1), cnt)
+    for b in sub:
+        assert (tab[b, idx[b, :cnt[b]]] == 1).all()
+        j = cnt[b] - 1
+        assert torch.equal(out["mem"][b, j], inp.s[b, idx[b, j]])
+        assert out["scores_gather"][b, j].item() == out["scores"][b, idx[b, j]].item()
+    # gradients: finite; S only receives gradient at fired frames; the scorer gradient is not the quantity part alone
+    assert torch.isfinite(out["loss"]).item()
+    for p in scorer.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+    ds = inp.s.grad.float().abs().sum(-1).cpu().numpy()
+    fired = np.zeros((B, T), dtype=bool)
+    for b in range(B):
+        fired[b, idx[b, :cnt[b]]] = True
+    assert (ds[~fired] == 0).all() and (ds[fired] > 0).mean() > 0.99
+    assert inp.x.grad is None
+    for q in inp.qs:
+        assert torch.isfinite(q.grad).all()
+    # one layer again with the debug probabilities: masked keys and (ILK) keys j > i + 2 are exact zeros, rows sum
+    # to one, and the bias gradient sums to zero over the live keys of a row (softmax is shift invariant)
+    K = idx.shape[1]
+    kk = out["mem"].detach().view(B, K, h, d // h).permute(0, 2, 1, 3)
+    bias = out["scores_gather"].detach().clone().requires_grad_()
+    o1, p1 = ops.xattn(inp.qs[0].detach(), kk, kk, bias=bias, key_len=out["counts"], ilk_diag=2 if use_ilk else -1,
+                       need_probs=True)
+    dead = torch.arange(K, device=DEV)[None, :] >= out["counts"][:, None]
+    assert (p1.permute(0, 3, 1, 2)[dead] == 0).all()
+    if use_ilk:
+        banned = torch.arange(K, device=DEV)[None, :] > torch.arange(L, device=DEV)[:, None] + 2
+        assert (p1[:, :, banned] == 0).all()
+    dev_ = (p1.sum(-1) - 1).abs()
+    assert (dev_ < 1e-4).all(), (dev_.max().item(), (dev_ >= 1e-4).nonzero()[:8].tolist(), out["counts"].tolist())
+    o1.backward(torch.randn_like(o1))
+    live = (~dead).float()
+    tot = (bias.grad * live).sum(1).abs()
+    # delta = <O, dO> is formed from the bf16-rounded O, so a row's sum is zero up to 2^-9 of its terms
+    assert (tot <= 5e-3 * (bias.grad * live).abs().sum(1) + 1e-6).all() and (bias.grad[dead] == 0).all()
+    if use_ilk:
+        # query i sees keys j <= i + 2 only: the gradient of the LAST key of a long memory must not depend on G rows
+        # of early queries -> zeroing those cotangent rows leaves dS at that key unchanged
+        b = 0
+        last = idx[b, cnt[b] - 1]
+        ref_row = inp.s.grad[b, last].clone()
+        gs_saved = [g.clone() for g in inp.gs]
+        cut = max(cnt[b] - 4, 0)
+        for g in inp.gs:
+            g[b, :, :min(cut, g.shape[2])] = 0
+        for t in [inp.s] + inp.qs + list(scorer.parameters()):
+            t.grad = None
+        nugget_step_simul(scorer, inp, use_ilk=True)
+        if cut >= 1 and cut <= inp.gs[0].shape[2]:
+            assert torch.equal(inp.s.grad[b, last], ref_row)
+        for g, s_ in zip(inp.gs, gs_saved):
+            g.copy_(s_)
+    return out
+
+
+def test_full_size_simul_config2(ops):
+    """BASELINE.json configs[2]: B = 64, MuST-C-shaped log-normal lengths up to 1500 frames, L_b = 0.075 n_b + 2."""
+    rng = np.random.default_rng(4321)
+    B, T = 64, 1500
+    n = np.clip(np.round(50.0 * rng.lognormal(np.log(6.0), 0.6, size=B)), 50, T).astype(int)
+    n[0] = T
+    tl = np.clip(np.round(0.075 * n) + 2, 4, 512).astype(int)
+    _simul_full_size(ops, B, T, [int(v) for v in n], [int(v) for v in tl], False, 11)
+
+
+def test_full_size_simul_config3(ops):
+    """BASELINE.json configs[3]: B = 16, T = 3000, L = 227, infinite-lookback mask on."""
+    _simul_full_size(ops, 16, 3000, [3000] * 16, [227] * 16, True, 12)
