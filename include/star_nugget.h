@@ -142,6 +142,23 @@ int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask, const int3
                        const float* scores, int B, int T, int cap, int64_t* idx_out,
                        uint8_t* mask_out, int32_t* counts, int32_t* max_count,
                        float* scores_gather, void* stream);
+/* ---------------------------------------------------------------- f4: streaming fire decision
+ * The same recurrence fed one chunk of frames at a time (online fire decision; the
+ * reference runs apply_threshold_yield_nugget, w2v_simul.py:376-403, on whole utterances only, so this entry point
+ * has no call site there: its contract is "any chunking of a row gives the fires of star_cif_fire_scan on the whole
+ * row, bit for bit").  The fp32 integrator and the number of frames consumed are carried per utterance:
+ *   alpha_chunk [B,Tc] fp32    the next Tc frames of every utterance (frames at or beyond the utterance's length
+ *                              count as masked: weight 0)
+ *   lengths     [B] int32      utterance lengths in ABSOLUTE frames; the frame lengths[b]-1 always fires.  While an
+ *                              utterance's end is not known yet pass INT32_MAX
+ *   score_chunk optional [B,Tc] fp32 scorer logits of the chunk: scores_gather[b,j] = score at the j-th fire
+ *   state_cur   [B] fp32  in/out  integrator carry (0 before the first chunk)
+ *   state_pos   [B] int32 in/out  frames consumed so far (0 before the first chunk; += Tc per call)
+ * Outputs: idx_out [B,cap] int64 ABSOLUTE positions of this chunk's fires, ascending, -1 padded; counts [B] int32
+ * fires in this chunk (fires beyond cap are dropped but counted); scores_gather [B,cap] fp32 or NULL. */
+int star_cif_fire_step(const float* alpha_chunk, const int32_t* lengths, const float* score_chunk, int B,
+                       int Tc, float* state_cur, int32_t* state_pos, int cap, int64_t* idx_out,
+                       int32_t* counts, float* scores_gather, void* stream);
 /* block_attn_mask[b,i,j] = 1.0f iff prev_fire(i) < j <= i and frame i valid (w2v_simul.py:382-402),
  * built on demand from the fire positions.  idx [B,cap] int64 (-1 padded), counts [B] int32,
  * out [B,T,T] fp32. */

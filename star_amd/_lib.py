@@ -54,6 +54,7 @@ SIGNATURES = {
     "star_cif_resize": (_I, [_P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "star_cif_resize_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "star_cif_fire_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_aggregate_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

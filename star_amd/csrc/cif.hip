@@ -200,25 +200,34 @@ static inline int scan_rows_per_wg(int B, int T) {
     return r;
 }
 
+// state_cur / state_pos (both null for the whole-utterance scan): the streaming form of row f4.  The T frames are the
+// chunk that follows state_pos[b] frames already consumed; lengths[] stays the utterance length in absolute frames,
+// positions are written as absolute frame numbers, the integrator is carried in from and out to state_cur[b].
 __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
     const float* __restrict__ alphas, const uint8_t* __restrict__ attn_mask, const int32_t* __restrict__ lengths,
     const float* __restrict__ scores, int B, int T, int cap, int R, int64_t* __restrict__ idx_out,
     uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
-    float* __restrict__ scores_gather) {
+    float* __restrict__ scores_gather, float* __restrict__ state_cur, int32_t* __restrict__ state_pos) {
     extern __shared__ __attribute__((aligned(16))) float fs_rows[];       // [R][pitch] alphas * mask -> integrals
-    __shared__ int lens[8], wtot[4];
+    __shared__ int lens[8], wtot[4], slow[8];
     const int pitch = scan_pitch(T), T16 = (T + 15) & ~15;
     float* thr_rows = fs_rows + (size_t)R * pitch;                        // [R][pitch] per-frame thresholds
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * R;
     const int nrows = min(R, B - b0);
-    if (tid < 8) lens[tid] = 0;
+    if (tid < 8) {
+        lens[tid] = 0;
+        slow[tid] = 0;
+    }
     __syncthreads();
     // phase 1 (all threads, coalesced): rows -> LDS, valid-frame counts (== attn_mask.sum(1) of the reference)
     for (int r = 0; r < nrows; ++r) {
         const size_t base = (size_t)(b0 + r) * T;
-        const int n_r = attn_mask ? 0 : min(lengths[b0 + r], T);
+        const int pos0 = state_pos ? state_pos[b0 + r] : 0;
+        // frames of this chunk that are valid: [0, n_r)
+        const int n_r = attn_mask ? 0 : max(min((int64_t)lengths[b0 + r] - pos0, (int64_t)T), (int64_t)0);
         int c = 0;
+        bool odd = false;                                  // a weight outside {0} u [FLT_MIN, 1] (NaN included)
         for (int t = tid; t < T16; t += 256) {
             float v = 0.0f;
             if (t < T) {
@@ -226,32 +235,57 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
                 const bool valid = attn_mask ? (attn_mask[base + t] != 0) : (t < n_r);
                 v = valid ? a : a * 0.0f;                  // alphas * attn_mask (keeps NaN/inf of the product)
                 c += valid ? 1 : 0;
+                odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v <= 1.0f));
             }
             fs_rows[r * pitch + t] = v;
         }
+        if (odd) slow[r] = 1;
         if (attn_mask) {
             c = wave_sum(c);
             if ((tid & 63) == 0) atomicAdd(&lens[r], c);
         } else if (tid == 0) {
-            // unclamped: a length > T means "every frame valid and NO forced last-frame fire" (the threshold row
-            // below then has no -inf inside [0, T); get_valid_mask_indices relies on it)
-            lens[r] = lengths[b0 + r];
+            // unclamped: a length beyond the last frame means "every frame valid and NO forced last-frame fire" (the
+            // threshold row below then has no -inf inside [0, T); get_valid_mask_indices and the streaming step rely
+            // on it).  Relative to this chunk; clamped below so that the int cannot overflow.
+            const int64_t rel = (int64_t)lengths[b0 + r] - pos0;
+            lens[r] = (int)max(min(rel, (int64_t)T + 1), (int64_t)-1);
         }
     }
     __syncthreads();
     for (int r = 0; r < nrows; ++r) {
         const int n = lens[r];
-        for (int t = tid; t < T16; t += 256) thr_rows[r * pitch + t] = (n == t + 1) ? -__builtin_inff() : 1.0f;
+        bool late = false;                                 // a non-zero weight after the forced fire (mask with holes)
+        for (int t = tid; t < T16; t += 256) {
+            // frames T..T16 are padding of the LDS row, not frames of the utterance: they never fire, so the carry
+            // handed to the next chunk is the carry after frame T-1
+            thr_rows[r * pitch + t] = t >= T ? __builtin_inff() : ((n == t + 1) ? -__builtin_inff() : 1.0f);
+            late |= (t >= n && n >= 1 && fs_rows[r * pitch + t] != 0.0f);
+        }
+        if (late) slow[r] = 1;
     }
     __syncthreads();
     // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r
-    if (tid < nrows) cif_serial_chain<true>(fs_rows + tid * pitch, thr_rows + tid * pitch, 1.0f, T16 >> 4);
+    if (tid < nrows) {
+        const float c0 = state_cur ? state_cur[b0 + tid] : 0.0f;
+        const bool unit = !slow[tid] && (c0 == 0.0f || (c0 >= 1.17549435e-38f && c0 < 1.0f));
+        float c1;
+        if (unit) {
+            c1 = cif_serial_chain_unit(fs_rows + tid * pitch, T16 >> 4, c0);
+            // the forced fire subtracts 1 whatever the integral was; every later weight of the chunk is zero
+            const int n = lens[tid];
+            if (n >= 1 && n <= T) c1 = __fsub_rn(fs_rows[tid * pitch + n - 1], 1.0f);
+        } else {
+            c1 = cif_serial_chain<true>(fs_rows + tid * pitch, thr_rows + tid * pitch, 1.0f, T16 >> 4, c0);
+        }
+        if (state_cur) state_cur[b0 + tid] = c1;
+    }
     __syncthreads();
     // phase 3 (all threads): fire_t = (I_t >= thr_t) for t < T; ascending positions by an exclusive scan over
     // contiguous chunks of frames; pad slots carry index -1 == frame T-1
     const int C = (T + 255) / 256;
     for (int r = 0; r < nrows; ++r) {
         const int b = b0 + r;
+        const int pos0 = state_pos ? state_pos[b] : 0;
         const float* ir = fs_rows + r * pitch;
         const float* tr = thr_rows + r * pitch;
         const int lo = min(tid * C, T), hi = min(lo + C, T);
@@ -262,7 +296,7 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
         for (int t = lo; t < hi; ++t) {
             if (ir[t] >= tr[t]) {
                 if (slot < cap) {
-                    idx_out[(size_t)b * cap + slot] = t;
+                    idx_out[(size_t)b * cap + slot] = (int64_t)pos0 + t;
                     if (mask_out) mask_out[(size_t)b * cap + slot] = 1;
                     if (scores_gather) scores_gather[(size_t)b * cap + slot] = scores[(size_t)b * T + t];
                 }
@@ -280,6 +314,8 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
             if (scores_gather) scores_gather[(size_t)b * cap + j] = last_score;
         }
     }
+    __syncthreads();                                       // every thread has read state_pos[b] before it moves
+    if (state_pos && tid < nrows) state_pos[b0 + tid] += T;
 }
 
 // block_attn_mask rows: out[b,i,j] = (prev_fire(i) < j <= i) && valid(i)
@@ -390,8 +426,33 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
         }
     }
     hipLaunchKernelGGL(cif_fire_scan_kernel, dim3(cdiv(B, R)), dim3(256), smem, (hipStream_t)stream, alphas, attn_mask,
-                       lengths, scores, B, T, cap, R, idx_out, mask_out, counts, max_count, scores_gather);
+                       lengths, scores, B, T, cap, R, idx_out, mask_out, counts, max_count, scores_gather,
+                       (float*)nullptr, (int32_t*)nullptr);
     STAR_LAUNCH_CHECK("star_cif_fire_scan");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_fire_step(const float* alpha_chunk, const int32_t* lengths, const float* score_chunk, int B,
+                                  int Tc, float* state_cur, int32_t* state_pos, int cap, int64_t* idx_out,
+                                  int32_t* counts, float* scores_gather, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(alpha_chunk && lengths && state_cur && state_pos && idx_out && counts, "star_cif_fire_step: null pointer");
+    STAR_REQUIRE(B >= 1 && Tc >= 1 && cap >= 1, "star_cif_fire_step: bad shape B=%d Tc=%d cap=%d", B, Tc, cap);
+    STAR_REQUIRE(!scores_gather || score_chunk, "star_cif_fire_step: scores_gather requested without score_chunk");
+    STAR_REQUIRE(Tc <= 16384, "star_cif_fire_step: Tc=%d exceeds the 16384-frame LDS row limit", Tc);
+    const int R = scan_rows_per_wg(B, Tc);
+    const size_t smem = (size_t)R * scan_pitch(Tc) * 8;
+    if (smem > 48 * 1024) {
+        static DevOnce once;
+        if (!reserve_lds_once(once, (const void*)cif_fire_scan_kernel, 152 * 1024)) {
+            set_error("star_cif_fire_step: cannot reserve LDS");
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(cif_fire_scan_kernel, dim3(cdiv(B, R)), dim3(256), smem, (hipStream_t)stream, alpha_chunk,
+                       (const uint8_t*)nullptr, lengths, score_chunk, B, Tc, cap, R, idx_out, (uint8_t*)nullptr, counts,
+                       (int32_t*)nullptr, scores_gather, state_cur, state_pos);
+    STAR_LAUNCH_CHECK("star_cif_fire_step");
     return STAR_OK;
 }
 

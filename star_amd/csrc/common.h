@@ -78,9 +78,10 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // per frame add, subtract, compare, select; the row is OVERWRITTEN with the pre-fire integrals I_t (after the add),
 // from which all threads afterwards recover fires (I_t >= thr_t), positions and weights in parallel.
 // HAS_THR = false: the constant threshold thr_const for every frame (thr_row unused).
+// cur is the integrator carried in (0 at the start of an utterance); the carry after the last frame is returned.
 template <bool HAS_THR>
-__device__ __forceinline__ void cif_serial_chain(float* row, const float* thr_row, float thr_const, int nblk16) {
-    float cur = 0.0f;
+__device__ __forceinline__ float cif_serial_chain(float* row, const float* thr_row, float thr_const, int nblk16,
+                                                  float cur = 0.0f) {
     f32x4 a[4], th[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -112,6 +113,37 @@ __device__ __forceinline__ void cif_serial_chain(float* row, const float* thr_ro
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a[q] = an[q]; th[q] = tn[q]; }
     }
+    return cur;
+}
+
+// The same chain for the common case -- threshold 1 on every frame, every weight in {0} u [FLT_MIN, 1], carry in
+// {0} u [FLT_MIN, 1): then I = cur + a lies in [0, 2), and "I >= 1 ? I - 1 : I" is fract(I) EXACTLY (I - 1 is exact
+// for I in [1, 2) by Sterbenz, no denormal can appear).  Two dependent instructions per frame (v_add_f32, v_fract_f32)
+// instead of four.  The caller checks the precondition; a forced fire (threshold -inf) is legal only where every later
+// weight is zero, where the two recurrences can no longer produce different fires.
+__device__ __forceinline__ float cif_serial_chain_unit(float* row, int nblk16, float cur) {
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(row + 4 * q);
+    for (int blk = 0; blk < nblk16; ++blk) {
+        f32x4 an[4];
+        const int nb = (blk + 1 < nblk16) ? blk + 1 : blk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[q] = *(const f32x4*)(row + 16 * nb + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = __fadd_rn(cur, a[q][j]);
+                a[q][j] = t;
+                cur = __builtin_amdgcn_fractf(t);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4*)(row + 16 * blk + 4 * q) = a[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = an[q];
+    }
+    return cur;
 }
 
 // exclusive scan of one int per thread over a 256-thread workgroup (wtot: 4 ints of LDS); `total` = workgroup sum

@@ -317,6 +317,37 @@ def cif_fire_scan(alphas, attn_mask=None, lengths=None, cap: Optional[int] = Non
     return idx, m.view(torch.bool), counts, mx, sg
 
 
+class FireState:
+    """Per-utterance state of the streaming fire decision: the fp32 integrator and the frames consumed so far."""
+
+    def __init__(self, batch: int, device):
+        self.cur = torch.zeros(batch, dtype=torch.float32, device=device)
+        self.pos = torch.zeros(batch, dtype=torch.int32, device=device)
+
+
+def cif_fire_step(alpha_chunk, lengths, state: FireState, cap: Optional[int] = None, scores=None):
+    """Streaming form of cif_fire_scan: feeds the next chunk [B,Tc] of weights; the fires of any
+    chunking equal the whole-utterance scan bit for bit.  lengths [B] int32: utterance lengths in absolute frames
+    (INT32_MAX while the end is unknown).  Returns (idx [B,cap] int64 ABSOLUTE positions, -1 padded, counts [B] int32,
+    scores_gather or None); updates `state` in place.  No host sync."""
+    _need_cuda(alpha_chunk, lengths, scores)
+    a = alpha_chunk.detach().to(torch.float32).contiguous()
+    B, Tc = a.shape
+    cap = Tc if cap is None else int(cap)
+    if state.cur.shape[0] != B or state.cur.device != a.device:
+        raise ValueError("cif_fire_step: state belongs to another batch / device")
+    ln = lengths.to(torch.int32).contiguous()
+    idx = torch.empty((B, cap), dtype=torch.int64, device=a.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=a.device)
+    sc = sg = None
+    if scores is not None:
+        sc = scores.detach().to(torch.float32).contiguous()
+        sg = torch.empty((B, cap), dtype=torch.float32, device=a.device)
+    check(lib().star_cif_fire_step(ptr(a), ptr(ln), ptr(sc), B, Tc, ptr(state.cur), ptr(state.pos), cap, ptr(idx),
+                                   ptr(counts), ptr(sg), stream_ptr()), "star_cif_fire_step")
+    return idx, counts, sg
+
+
 def cif_block_mask(idx, counts, attn_mask=None, lengths=None, T: Optional[int] = None):
     """block_attn_mask [B,T,T] fp32 (w2v_simul.py:382-402), built on demand from the fire positions."""
     _need_cuda(idx, counts, attn_mask, lengths)

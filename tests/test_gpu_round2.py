@@ -561,3 +561,151 @@ def test_full_size_simul_config2(ops):
 def test_full_size_simul_config3(ops):
     """BASELINE.json configs[3]: B = 16, T = 3000, L = 227, infinite-lookback mask on."""
     _simul_full_size(ops, 16, 3000, [3000] * 16, [227] * 16, True, 12)
+
+
+# ------------------------------------------------------------------------------------------------ f4: streaming
+def _chunked_fires(ops, alphas, lengths, chunks, late_length=False):
+    """Feed [B,T] weights through star_cif_fire_step in the given chunk sizes; returns per-row lists of positions."""
+    B, T = alphas.shape
+    st = ops.FireState(B, DEV)
+    ln = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    unknown = torch.full_like(ln, 2 ** 31 - 1)
+    fires = [[] for _ in range(B)]
+    off = 0
+    for c in chunks:
+        chunk = alphas[:, off:off + c].contiguous()
+        # late_length: the end of an utterance only becomes known with the chunk that holds its last frame
+        cur_len = torch.where(ln <= off + c, ln, unknown) if late_length else ln
+        idx, cnt, _ = ops.cif_fire_step(chunk, cur_len, st, cap=c)
+        idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+        for b in range(B):
+            assert (idx[b, cnt[b]:] == -1).all()
+            fires[b].extend(int(v) for v in idx[b, :cnt[b]])
+        off += c
+    assert off == T and (st.pos.cpu().numpy() == T).all()
+    return fires, st
+
+
+def _chunkings(T, rng):
+    out = [[T], [1] * T if T <= 64 else [T // 2, T - T // 2], [16] * (T // 16) + ([T % 16] if T % 16 else [])]
+    for _ in range(3):
+        sizes, left = [], T
+        while left:
+            c = int(min(left, rng.integers(1, 200)))
+            sizes.append(c)
+            left -= c
+        out.append(sizes)
+    return out
+
+
+@pytest.mark.parametrize("name", ["cif_plain", "cif_fixup", "cif_ragged"])
+def test_fire_step_any_chunking_of_the_goldens(ops, name):
+    """f4 first slice: any chunking of the reference's own scan inputs (w2v_simul.py:376-403 goldens) gives the
+    reference's fire positions bit for bit, whether the utterance length is known from the start or only at its end."""
+    g = load(name)
+    lengths = g["lengths"].astype(np.int64)
+    alphas = dev(g["resized"].astype(np.float32))
+    gold = g["nugget_indices"]
+    rng = np.random.default_rng(0)
+    for chunks in _chunkings(alphas.shape[1], rng):
+        for late in (False, True):
+            fires, _ = _chunked_fires(ops, alphas, lengths, chunks, late)
+            for b in range(alphas.shape[0]):
+                assert fires[b] == [int(v) for v in gold[b] if v >= 0], (name, chunks[:4], late, b)
+
+
+def test_fire_step_random_vs_whole_scan_and_oracle(ops):
+    """Random rows through both recurrences of the kernel: weights in [0, 1] (v_fract chain), rows with weights above
+    1, denormal weights and a carry >= 1 at a chunk border (generic chain).  Whole scan == oracle == any chunking, and
+    the carried integrator equals the oracle's carry."""
+    rng = np.random.default_rng(7)
+    B, T = 12, 1000
+    a = (rng.random((B, T)) * 0.3).astype(np.float32)
+    a[1, ::7] = 0.0
+    a[2] *= 6.0                                   # weights up to 1.8: several fires' worth of carry
+    a[3, 100:110] = 2.5
+    a[4, :50] = 1e-41                             # denormals
+    a[5] = 0.0
+    a[6, 499] = 1.0
+    a[7] = np.float32(1.0)
+    lengths = [T, 900, T, T, 333, 10, 500, 64, 1, T, 17, 999]
+    mask = lmask(lengths, T)
+    o_mask, o_idx, _ = orc.fire_scan(a, mask, with_block_mask=False)
+    ad = dev(a)
+    ln = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    widx, _, wcnt, _, _ = ops.cif_fire_scan(ad, lengths=ln, cap=T)
+    widx, wcnt = widx.cpu().numpy(), wcnt.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(widx[b, :wcnt[b]], o_idx[b, :o_mask[b].sum()])
+    # the oracle's carry after the last frame (same recurrence as orc.fire_scan)
+    carry = np.zeros(B, dtype=np.float32)
+    am = a * mask
+    for t in range(T):
+        carry = (carry + am[:, t]).astype(np.float32)
+        f = (carry >= 1) | (np.asarray(lengths) == t + 1)
+        carry = np.where(f, (carry - np.float32(1)).astype(np.float32), carry)
+    for chunks in _chunkings(T, rng) + [[499, 1, 500], [3] * 333 + [1]]:
+        fires, st = _chunked_fires(ops, ad, lengths, chunks, late_length=True)
+        for b in range(B):
+            assert fires[b] == [int(v) for v in o_idx[b, :o_mask[b].sum()]], (chunks[:4], b)
+        np.testing.assert_array_equal(st.cur.cpu().numpy(), carry)
+
+
+def test_streaming_segmenter_matches_offline(ops):
+    """Incremental scorer + online fire decision + memory append (star_amd.streaming) against the same kernels run on
+    the whole utterances: fire positions, memory rows, logits, counts; and the write policy: token i decoded from the
+    partial memory as soon as tokens_ready() allows equals row i of the offline infinite-lookback attention."""
+    from star_amd.nugget import NuggetScorer
+    from star_amd.streaming import StreamingNuggetSegmenter
+    torch.manual_seed(3)
+    B, T, d, h = 3, 640, 256, 2
+    lengths = [640, 500, 130]
+    scorer = NuggetScorer(d).to(DEV)
+    with torch.no_grad():
+        scorer[2].bias.fill_(-2.0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, d, generator=g).to(torch.bfloat16).to(DEV)
+    s = torch.randn(B, T, d, generator=g).to(torch.bfloat16).to(DEV)
+    ln = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        scores = scorer(x).squeeze(-1).float()
+    alphas, _ = ops.cif_quantity(scores, torch.zeros_like(ln), lengths=ln)
+    idx, nmask, counts, _, sg = ops.cif_fire_scan(alphas, lengths=ln, cap=T, scores=scores)
+    kmax = int(counts.max().item())
+    mem_off = ops.gather_rows(s, idx[:, :kmax])
+    seg = StreamingNuggetSegmenter(scorer, B, d, max_nuggets=kmax + 4, device=DEV)
+    q = torch.randn(B, h, 40, d // h, generator=g).to(torch.bfloat16).to(DEV)
+    k_off = mem_off.view(B, kmax, h, d // h).permute(0, 2, 1, 3)
+    o_off, _ = ops.xattn(q, k_off, k_off, bias=sg[:, :kmax].contiguous(), key_len=counts, ilk_diag=2)
+    checked = 0
+    off = 0
+    for c in [64, 100, 36, 200, 1, 111, 128]:
+        known = torch.where(ln <= off + c, ln, torch.full_like(ln, 2 ** 31 - 1))
+        seg.push(x[:, off:off + c].contiguous(), s[:, off:off + c].contiguous(), lengths=known)
+        off += c
+        mem, msc, mpos, mcnt = seg.memory()
+        ready = seg.tokens_ready().cpu().numpy()
+        m = mcnt.cpu().numpy()
+        for b in range(B):
+            if off < lengths[b]:
+                assert ready[b] == max(m[b] - 2, 0)
+            else:
+                assert ready[b] == 2 ** 31 - 1
+            i = min(int(ready[b]), q.shape[2]) - 1           # the newest token that may be written for row b
+            if i < 0:
+                continue
+            kk = mem[b:b + 1].view(1, -1, h, d // h).permute(0, 2, 1, 3)
+            o_i, _ = ops.xattn(q[b:b + 1, :, i:i + 1].contiguous(), kk, kk, bias=msc[b:b + 1].contiguous(),
+                               key_len=mcnt[b:b + 1], ilk_diag=seg.ilk_diag_for(i))
+            ref = o_off[b, :, i].float()
+            assert (o_i[0, :, 0].float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-3
+            checked += 1
+    assert off == T and checked >= 10
+    mem, msc, mpos, mcnt = seg.memory()
+    assert torch.equal(mcnt, counts)
+    for b in range(B):
+        n = int(counts[b])
+        assert torch.equal(mpos[b, :n], idx[b, :n])
+        assert torch.equal(mem[b, :n], mem_off[b, :n])
+        assert torch.equal(msc[b, :n], sg[b, :n])
+    assert bool(seg.finished().all())
