@@ -27,6 +27,11 @@
 // Algorithmic work: forward 2*N_f*d*(d+1) FLOP; bytes: X 2*d*N_f + W1 2*d*d read, scores 4*N_f written.
 #include "common.h"
 
+#ifndef STAR_GEMM_ABL
+#define STAR_GEMM_ABL 0      // diagnostic builds (tools/build_abl.sh): 1 no DMA in the K loop, 2 no ds_reads, 4 no epilogue,
+                             // 8 every tile reads one of 8 cache-hot A panels
+#endif
+
 namespace star {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -114,6 +119,77 @@ __device__ __forceinline__ u32x4 ep_read_mrow(const uint8_t* W, int mb, int nh, 
     return *(u32x4*)&r;
 }
 
+// EPI_SCORE epilogue of one 256 x 256 tile (shared by the two scorer-forward kernels): ReLU / bias / w2 row dot into
+// per-column-tile partial scores, and the ReLU sign bits.  Persistent mode: the next tile's operands are landing in
+// the ring right now, so the row reduction has its own LDS behind it and uses raw barriers (a __syncthreads() would
+// drain the DMA queue).
+__device__ __forceinline__ void score_epilogue(f32x4 (&acc)[TM][TN], const GemmParams& p, uint8_t* lds,
+                                               const float* bw_lds, bool bw_staged, int m_tile, int n_tile, int nbn) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
+    const int wrow0 = wr * 128, wcol0 = wc * 64;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    float* red = (float*)(lds + GEMM_LDS);
+    float bb[TN], ww[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wcol0 + tn * 16 + ccol;
+        if (bw_staged) {
+            bb[tn] = bw_lds[n];
+            ww[tn] = bw_lds[SCORE_BW_MAXN + n];
+        } else {
+            bb[tn] = n < p.N ? p.b1[n] : 0.f;
+            ww[tn] = n < p.N ? p.w2[n] : 0.f;
+        }
+    }
+    // ReLU sign bits (all the backward needs of H) are packed per lane while the row dot is formed: element
+    // e = (tm*4 + tn)*4 + j goes to bit 31 - e%32 of the lane's dword e/32 (v_alignbit shifts in the sign of -h)
+    uint32_t hb[TM / 2] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        float srow[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = acc[tm][tn][j] + bb[tn];
+                srow[j] += fmaxf(h, 0.f) * ww[tn];
+                hb[tm >> 1] = __builtin_amdgcn_alignbit(hb[tm >> 1], __float_as_uint(0.f - h), 31);
+            }
+        // sum over the 16 lanes that share a row: rotations by 8, 4, 2, 1 inside the DPP row leave the total in every
+        // lane (four v_add_f32_dpp per value; __shfl_xor would be a chain of ds_bpermute round trips: 128 per tile,
+        // each waited for, 6 us of the 32 us a tile took)
+#define STAR_ROR_ADD(CTRL)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+        srow[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(srow[j]), (CTRL), 0xF, 0xF, false))
+        STAR_ROR_ADD(0x128);
+        STAR_ROR_ADD(0x124);
+        STAR_ROR_ADD(0x122);
+        STAR_ROR_ADD(0x121);
+#undef STAR_ROR_ADD
+        // lane ccol = j of each 16-lane group stores row j of the group's four rows
+        const float v01 = ccol == 0 ? srow[0] : srow[1], v23 = ccol == 2 ? srow[2] : srow[3];
+        if (ccol < 4) red[(wrow0 + tm * 16 + crow4 + ccol) * 4 + wc] = ccol < 2 ? v01 : v23;
+    }
+    if (p.relu_bits) {
+        // tile blob: [wave 8][plane 4][lane 64] dwords -> every store instruction writes 256 contiguous bytes
+        uint32_t* dst = p.relu_bits + ((int64_t)(m_tile * nbn + n_tile) * NWAVE + wid) * (TM / 2) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < TM / 2; ++q) dst[q * 64] = hb[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's partial sums are in LDS
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    static_assert(BM <= GEMM_THREADS, "one thread per tile row");
+    if (tid < BM) {
+        const f32x4 rr = *(const f32x4*)(red + tid * 4);
+        p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
+    }
+    // (the next write to `red` is a whole K loop of barriers away)
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -157,7 +233,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int hr = (wid * 2 + i) * 8 + (lane >> 3);
-                int am = mm0 + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
+                int am = ((STAR_GEMM_ABL & 8) ? (mm0 & 2047) : mm0) + (hr >> 6) * 128 + hsel * 64 + (hr & 63);
                 if (am >= p.M) am = p.M - 1;
                 arow[hsel][i] = am;
             }
@@ -198,6 +274,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     // output tile of this workgroup (persistent mode).  UB = number of K tiles consumed so far: buffer parity.
 #define STAR_STAGE(KIND, TT)                                                                                 \
     do {                                                                                                     \
+        if ((STAR_GEMM_ABL & 1) && in_loop) break;                                                           \
         uint8_t* dst_ = lds + ((ubase + (TT)) & 1) * BUF_BYTES + (KIND) * HALF_BYTES + wid * 2048;           \
         if ((TT) < nk) {                                                                                     \
             glds16(src[KIND][0] + (int64_t)(TT) * BK, dst_);                                                 \
@@ -215,7 +292,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     const int a_off = (wr * 64 + frow) * ROW_BYTES;
     const int b_off = (wc * 32 + frow) * ROW_BYTES;
     bf16x8 af[4][2], bfr[2][2][2];      // A quadrant rows (reloaded per row half), B both column halves
+    if (STAR_GEMM_ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][0] = af[i][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[i][j][0] = bfr[i][j][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+    }
     auto read_a = [&](int buf, int mh) {
+        if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + a_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -224,6 +310,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         }
     };
     auto read_b0 = [&](int buf) {
+        if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + H_B0 * HALF_BYTES + b_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -232,6 +319,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         }
     };
     auto read_b1 = [&](int buf) {
+        if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + H_B1 * HALF_BYTES + b_off;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -258,6 +346,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     // ---- prologue: all of tile 0 and three half-tiles of tile 1 (seven half-tiles ahead, as in the loop)
     int ubase = 0;
     bool has_next = false;
+    bool in_loop = false;
+    (void)in_loop;
     STAR_STAGE(H_B0, 0);
     STAR_STAGE(H_A0, 0);
     STAR_STAGE(H_B1, 0);
@@ -301,6 +391,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier behind the first
     __builtin_amdgcn_sched_barrier(0);
 
+    in_loop = true;
     for (int t = 0; t < nk; ++t) {
         const int buf = (ubase + t) & 1;
         // phase 1: quadrant (0,0).  The four B reads go first so that lgkmcnt(8) retires them before the barrier:
@@ -335,62 +426,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
     const int wrow0 = wr * 128, wcol0 = wc * 64;      // this wave's corner inside the tile
 
-    if constexpr (EPI == EPI_SCORE) {
-        // persistent mode: the next tile's operands are landing in the ring right now, so the row reduction has
-        // its own LDS behind it and uses raw barriers (a __syncthreads() would drain the DMA queue)
-        float* red = (float*)(lds + GEMM_LDS);
-        float bb[TN], ww[TN];
+    if constexpr (EPI == EPI_SCORE && (STAR_GEMM_ABL & 4)) {
+        float keep = 0.f;                                  // keep every accumulator alive
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wcol0 + tn * 16 + ccol;
-            if (bw_staged) {
-                bb[tn] = bw_lds[n];
-                ww[tn] = bw_lds[SCORE_BW_MAXN + n];
-            } else {
-                bb[tn] = n < p.N ? p.b1[n] : 0.f;
-                ww[tn] = n < p.N ? p.w2[n] : 0.f;
-            }
-        }
-        // ReLU sign bits (all the backward needs of H) are packed per lane while the row dot is formed: element
-        // e = (tm*4 + tn)*4 + j goes to bit 31 - e%32 of the lane's dword e/32 (v_alignbit shifts in the sign of -h)
-        uint32_t hb[TM / 2] = {0u, 0u, 0u, 0u};
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            float srow[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float h = acc[tm][tn][j] + bb[tn];
-                    srow[j] += fmaxf(h, 0.f) * ww[tn];
-                    hb[tm >> 1] = __builtin_amdgcn_alignbit(hb[tm >> 1], __float_as_uint(0.f - h), 31);
-                }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float s = srow[j];
-                // sum over the 16 lanes that share this row
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
-                s += __shfl_xor(s, 8, 64);
-                if (ccol == 0) red[(wrow0 + tm * 16 + crow4 + j) * 4 + wc] = s;
-            }
-        }
-        if (p.relu_bits) {
-            // tile blob: [wave 8][plane 4][lane 64] dwords -> every store instruction writes 256 contiguous bytes
-            uint32_t* dst = p.relu_bits + ((int64_t)(m_tile * nbn + n_tile) * NWAVE + wid) * (TM / 2) * 64 + lane;
-#pragma unroll
-            for (int q = 0; q < TM / 2; ++q) dst[q * 64] = hb[q];
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's partial sums are in LDS
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        static_assert(BM <= GEMM_THREADS, "one thread per tile row");
-        if (tid < BM) {
-            const f32x4 rr = *(const f32x4*)(red + tid * 4);
-            p.partial[(int64_t)n_tile * p.partial_ld + m0 + tid] = (rr[0] + rr[1]) + (rr[2] + rr[3]);
-        }
-        // (the next write to `red` is a whole K loop of barriers away)
+            for (int tn = 0; tn < TN; ++tn) keep += (acc[tm][tn][0] + acc[tm][tn][1]) + (acc[tm][tn][2] + acc[tm][tn][3]);
+        if (keep == 123.456f) p.partial[tid] = keep;
+    } else if constexpr (EPI == EPI_SCORE) {
+        score_epilogue(acc, p, lds, bw_lds, bw_staged, m_tile, n_tile, nbn);
     } else if constexpr (EPI == EPI_SLAB) {
         float* slab = p.slab + (int64_t)split * p.M * p.N;
 #pragma unroll
