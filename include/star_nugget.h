@@ -219,6 +219,20 @@ size_t star_scorer_relu_bits_bytes(int64_t N, int d);
 int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2,
                     const float* b2, int64_t N, int d, float* scores, void* relu_bits, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* Ragged form of star_scorer_fwd for a padded batch x [B*T, d] whose utterance b has lengths[b] valid frames (a
+ * prefix of its T rows): the reference scores every padded frame too (w2v_asr.py:553, w2v_simul.py:411) and masks them
+ * afterwards (alphas * mask, top-k on masked scores), so a pad frame's score is never observable; here it is 0 and its
+ * row tile is not computed when the whole 256-row tile is padding.
+ *   lengths    [B] int32 (device)   valid frames per utterance
+ *   live_tiles [n_live] int32 (device), ascending: the 256-row tiles (tile i = rows 256 i ..) that hold at least one
+ *              valid frame -- host code derives it from the lengths (star_amd.ops.ValidFrames); a tile that is not
+ *              listed gets scores 0 and unspecified relu_bits, so listing too few tiles loses frames without an error
+ * Everything else as star_scorer_fwd (relu_bits stays indexed by frame, so star_scorer_bwd takes it unchanged; pass
+ * it only row ids of valid frames). */
+int star_scorer_fwd_ragged(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                           const int32_t* lengths, int B, int T, int d, const int32_t* live_tiles, int n_live,
+                           float* scores, void* relu_bits, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* star_scorer_fwd without a workspace argument and without any allocation.  NO counterpart in the reference: it is
  * for callers that cannot allocate device memory around the call (code under HIP-graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  The partial scores go to a file-scope __device__ array of

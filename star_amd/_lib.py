@@ -62,6 +62,7 @@ SIGNATURES = {
     "star_scorer_fwd_workspace": (_SZ, [_I64, _I]),
     "star_scorer_relu_bits_bytes": (_SZ, [_I64, _I]),
     "star_scorer_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P]),
+    "star_scorer_fwd_ragged": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "star_scorer_fwd_static": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
     "star_scorer_bwd_workspace": (_SZ, [_I64, _I]),
     "star_scorer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P, _P,

@@ -73,6 +73,8 @@ struct GemmParams {
     float* partial;           // EPI_SCORE: [nbn][Mpad]
     int64_t partial_ld;
     uint32_t* relu_bits;      // EPI_SCORE (optional): sign bits of H in accumulator order (relu_bit_addr below)
+    const int32_t* live_tiles; // EPI_SCORE (optional): ascending ids of the row tiles to compute (ragged batches); the
+    int n_live;               // other row tiles are skipped altogether
     float* slab;              // EPI_SLAB: [splits][M][N]
     __bf16* out;              // EPI_ROWS: out[out_rows[m]][n]
     int64_t ldo;
@@ -208,6 +210,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         const int xcd = vb & 7, local = vb >> 3;
         const int panel = (local / nbn) * 8 + xcd;
         nt = local % nbn;
+        if (PERSIST && p.live_tiles) {
+            sp = 0;
+            if (panel >= p.n_live) return false;
+            mt = p.live_tiles[panel];
+            return true;
+        }
         mt = panel % nbm;
         sp = panel / nbm;
         return panel < nbm * p.splits;
@@ -496,10 +504,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 }
 
 // scores[m] = b2 + sum over column tiles of partial[t][m]   (fixed order -> reproducible)
+// lengths (ragged form): frame m = b*T + t is valid iff t < lengths[b]; the other frames get score 0 (their row tile
+// may not have been computed at all)
 __global__ void scorer_finish_kernel(const float* __restrict__ partial, int64_t ld, int ntiles,
-                                     const float* __restrict__ b2, int64_t N, float* __restrict__ scores) {
+                                     const float* __restrict__ b2, int64_t N, const int32_t* __restrict__ lengths, int T,
+                                     float* __restrict__ scores) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= N) return;
+    if (lengths && (int)(m % T) >= lengths[m / T]) {
+        scores[m] = 0.f;
+        return;
+    }
     float s = b2[0];
     for (int t = 0; t < ntiles; ++t) s += partial[(int64_t)t * ld + m];
     scores[m] = s;
@@ -746,7 +761,7 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
 
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
+    int grid = (((p.live_tiles ? p.n_live : nbm * p.splits) + 7) / 8) * 8 * nbn;
     static DevOnce once[4];
     static std::atomic<int> cus[64];
     int dev = 0;
@@ -838,15 +853,16 @@ extern "C" size_t star_scorer_relu_bits_bytes(int64_t N, int d) {
     return (size_t)(round_up(N, BM) / BM) * (size_t)((d + BN - 1) / BN) * (size_t)(BM * BN / 8);
 }
 
-extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
-                               int64_t N, int d, float* scores, void* relu_bits, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-    using namespace star;
-    STAR_REQUIRE(x && w1 && b1 && w2 && b2 && scores && workspace, "star_scorer_fwd: null pointer");
-    STAR_REQUIRE(N >= 1 && N < (1ll << 31) - BM, "star_scorer_fwd: bad N=%lld", (long long)N);
-    STAR_REQUIRE(d >= 128 && d % 128 == 0, "star_scorer_fwd: d=%d must be a multiple of 128", d);
+namespace star {
+static int scorer_fwd_impl(const char* who, const void* x, const void* w1, const float* b1, const float* w2,
+                           const float* b2, int64_t N, int d, const int32_t* lengths, int T, const int32_t* live_tiles,
+                           int n_live, float* scores, void* relu_bits, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    STAR_REQUIRE(x && w1 && b1 && w2 && b2 && scores && workspace, "%s: null pointer", who);
+    STAR_REQUIRE(N >= 1 && N < (1ll << 31) - BM, "%s: bad N=%lld", who, (long long)N);
+    STAR_REQUIRE(d >= 128 && d % 128 == 0, "%s: d=%d must be a multiple of 128", who, d);
     if (workspace_bytes < star_scorer_fwd_workspace(N, d)) {
-        set_error("star_scorer_fwd: workspace %zu < %zu bytes", workspace_bytes, star_scorer_fwd_workspace(N, d));
+        set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, star_scorer_fwd_workspace(N, d));
         return STAR_ERR_WORKSPACE;
     }
     GemmParams p = {};
@@ -862,14 +878,39 @@ extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, c
     p.w2 = w2;
     p.partial = (float*)workspace;
     p.partial_ld = round_up(N, BM);
-    STAR_REQUIRE(((uintptr_t)relu_bits & 15) == 0, "star_scorer_fwd: relu_bits must be 16-byte aligned");
+    STAR_REQUIRE(((uintptr_t)relu_bits & 15) == 0, "%s: relu_bits must be 16-byte aligned", who);
     p.relu_bits = (uint32_t*)relu_bits;
+    p.live_tiles = live_tiles;
+    p.n_live = n_live;
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;
+    if (!live_tiles || n_live > 0)
+        if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;
     hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
-                       p.partial_ld, (d + BN - 1) / BN, b2, N, scores);
-    STAR_LAUNCH_CHECK("star_scorer_fwd");
+                       p.partial_ld, (d + BN - 1) / BN, b2, N, lengths, T, scores);
+    STAR_LAUNCH_CHECK(who);
     return STAR_OK;
+}
+}  // namespace star
+
+extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                               int64_t N, int d, float* scores, void* relu_bits, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    return star::scorer_fwd_impl("star_scorer_fwd", x, w1, b1, w2, b2, N, d, nullptr, 1, nullptr, 0, scores, relu_bits,
+                                 workspace, workspace_bytes, stream);
+}
+
+extern "C" int star_scorer_fwd_ragged(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                                      const int32_t* lengths, int B, int T, int d, const int32_t* live_tiles, int n_live,
+                                      float* scores, void* relu_bits, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    using namespace star;
+    STAR_REQUIRE(lengths && live_tiles, "star_scorer_fwd_ragged: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1, "star_scorer_fwd_ragged: bad shape B=%d T=%d", B, T);
+    const int64_t N = (int64_t)B * T;
+    STAR_REQUIRE(n_live >= 0 && n_live <= (N + BM - 1) / BM, "star_scorer_fwd_ragged: n_live=%d for %lld row tiles", n_live,
+                 (long long)((N + BM - 1) / BM));
+    return scorer_fwd_impl("star_scorer_fwd_ragged", x, w1, b1, w2, b2, N, d, lengths, T, live_tiles, n_live, scores,
+                           relu_bits, workspace, workspace_bytes, stream);
 }
 
 extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2,

@@ -45,8 +45,11 @@ class NuggetScorer(nn.Sequential):
         consumed by that backward; every other forward/backward of this module runs dense (ops.ActiveRows)."""
         self.active_rows.set(rows)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:  # [B,T,d] -> [B,T,1]
-        s = ops.scorer(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias, self.active_rows)
+    def forward(self, x: torch.Tensor, valid: Optional["ops.ValidFrames"] = None) -> torch.Tensor:  # [B,T,d] -> [B,T,1]
+        """valid (optional, not in the reference): ops.ValidFrames of the padded batch -- pad frames get score 0 and
+        row tiles made of padding only are not computed.  Every consumer of the scores on the path masks pad frames
+        (w2v_asr.py:214-216, w2v_simul.py:421), so results do not change."""
+        s = ops.scorer(x, self[0].weight, self[0].bias, self[2].weight, self[2].bias, self.active_rows, valid)
         return s.to(x.dtype if x.dtype != torch.bfloat16 else torch.float32).unsqueeze(-1)
 
 

@@ -7,7 +7,7 @@ the STAR checkout (src/models/...).
 from __future__ import annotations
 
 import math
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
@@ -472,12 +472,41 @@ def _aux_stream(dev):
     return ent
 
 
+class ValidFrames:
+    """Host-known lengths of a padded batch [B,T,...] prepared once for the ragged scorer: the device copy of the
+    lengths, the 256-row tiles of the flattened [B*T] frame axis that hold a valid frame (what star_scorer_fwd_ragged
+    computes) and the flat ids of the valid frames (the active rows of a backward that reaches every valid frame, as
+    the quantity loss does).  Built from a host list, so using it costs no device->host sync (HIP-graph safe)."""
+
+    TILE = 256
+
+    def __init__(self, lengths: Sequence[int], T: int, device):
+        ln = np.minimum(np.asarray(list(lengths), dtype=np.int64), T)
+        self.B, self.T = int(ln.size), int(T)
+        starts = np.arange(self.B, dtype=np.int64) * T
+        live = set()
+        for b in range(self.B):
+            if ln[b] > 0:
+                live.update(range(int(starts[b] // self.TILE), int((starts[b] + ln[b] - 1) // self.TILE) + 1))
+        self.live_tiles = torch.tensor(sorted(live), dtype=torch.int32, device=device)
+        self.n_live = len(live)
+        rows = np.concatenate([starts[b] + np.arange(ln[b]) for b in range(self.B)]) if ln.sum() else np.zeros(0)
+        self.rows = torch.from_numpy(rows.astype(np.int32)).to(device)
+        self.lengths = torch.from_numpy(ln.astype(np.int32)).to(device)
+        self.n_valid = int(ln.sum())
+
+    def matches(self, x) -> bool:
+        return x.dim() == 3 and x.shape[0] == self.B and x.shape[1] == self.T
+
+
 class _Scorer(torch.autograd.Function):
     """scores = w2 . relu(W1 x + b1) + b2 (w2v_asr.py:113-117,553); bf16 MFMA, fp32 accumulate/scores."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, hint):
+    def forward(ctx, x, w1, b1, w2, b2, hint, valid=None):
         ctx.set_materialize_grads(False)
+        if valid is not None and not valid.matches(x):
+            raise ValueError(f"scorer: ValidFrames for [{valid.B},{valid.T}] used with input {tuple(x.shape)}")
         d = x.shape[-1]
         xb = x.detach()
         if xb.dtype != torch.bfloat16:
@@ -501,8 +530,14 @@ class _Scorer(torch.autograd.Function):
         # ReLU sign bits (1 bit per element of H): all the backward needs of the hidden activation
         bits = torch.empty((lib().star_scorer_relu_bits_bytes(N, d),), dtype=torch.uint8, device=dev) if need_grad else None
         scores = torch.empty((N,), dtype=torch.float32, device=dev)
-        check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(bits),
-                                    ptr(ws), wsb, stream_ptr()), "star_scorer_fwd")
+        if valid is None:
+            check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(bits),
+                                        ptr(ws), wsb, stream_ptr()), "star_scorer_fwd")
+        else:
+            check(lib().star_scorer_fwd_ragged(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), ptr(valid.lengths),
+                                               valid.B, valid.T, d, ptr(valid.live_tiles), valid.n_live, ptr(scores),
+                                               ptr(bits), ptr(ws), wsb, stream_ptr()), "star_scorer_fwd_ragged")
+        ctx.valid = valid
         ctx.save_for_backward(xb, w1b, w1ts, b1f, w2f, bits)
         ctx.hint = hint
         ctx.forward_id = hint._begin_forward() if hint is not None else 0
@@ -516,7 +551,7 @@ class _Scorer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         xb, w1b, w1ts, b1f, w2f, bits = ctx.saved_tensors
         N, d = xb.shape
         dev = xb.device
@@ -525,7 +560,9 @@ class _Scorer(torch.autograd.Function):
         if rows is not None and rows.numel() > N:
             raise ValueError(f"scorer backward: {rows.numel()} active rows for {N} frames (stale hint?)")
         if rows is None:
-            rows = torch.arange(N, dtype=torch.int32, device=dev)
+            # ragged forward: only valid frames have ReLU bits (and only they can carry a score gradient that matters:
+            # pad scores are constants)
+            rows = ctx.valid.rows if ctx.valid is not None else torch.arange(N, dtype=torch.int32, device=dev)
         rows = rows.to(torch.int32).contiguous().view(-1)
         R = rows.numel()
         need_dx = ctx.needs_input_grad[0] and w1ts is not None
@@ -545,13 +582,15 @@ class _Scorer(torch.autograd.Function):
                                     aux[2] if aux is not None else None), "star_scorer_bwd")
         t1, t2, t3, t4 = ctx.w_dtypes
         gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
-        return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None)
+        return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None, None)
 
 
-def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None):
-    """x [..., d] -> scores [...] fp32.  w1 [d,d] (nn.Linear layout), b1 [d], w2 [1,d], b2 [1]."""
+def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None, valid: Optional[ValidFrames] = None):
+    """x [..., d] -> scores [...] fp32.  w1 [d,d] (nn.Linear layout), b1 [d], w2 [1,d], b2 [1].
+    valid (x [B,T,d] padded): pad frames get score 0 and all-padding row tiles are skipped (star_scorer_fwd_ragged);
+    the reference scores them and masks the result everywhere it is used."""
     _need_cuda(x, w1, b1, w2, b2)
-    return _Scorer.apply(x, w1, b1, w2, b2, hint)
+    return _Scorer.apply(x, w1, b1, w2, b2, hint, valid)
 
 
 # ----------------------------------------------------------------------------- a8

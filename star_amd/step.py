@@ -34,6 +34,7 @@ class StepInputs:
     target_lengths: Optional[Sequence[int]] = None      # simul only (host)
     target_lengths_dev: Optional[torch.Tensor] = None
     cache: Optional[dict] = None    # per-rate device copies of host-derived tensors (kept out of the timed step)
+    valid: Optional["ops.ValidFrames"] = None           # ragged batches: lets the scorer skip all-padding row tiles
 
     def key_len_dev(self, rate):
         """k_b per utterance as an int32 device tensor (computed once per rate, outside any graph capture)."""
@@ -67,8 +68,9 @@ def make_inputs(lengths, T, d, h, L, nl, device, seed=1234, target_lengths=None,
     ld = torch.tensor(list(lengths), dtype=torch.int32, device=device)
     tl = None if target_lengths is None else torch.tensor(list(target_lengths), dtype=torch.int32, device=device)
     flat = torch.stack([t for pair in kv for t in pair]).contiguous()
+    valid = ops.ValidFrames(lengths, T, device) if (min(lengths) < T and x.is_cuda) else None
     return StepInputs(x, s, list(lengths), ld, qs, gs, kv, flat,
-                      None if target_lengths is None else list(target_lengths), tl)
+                      None if target_lengths is None else list(target_lengths), tl, None, valid)
 
 
 def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag, with_loss: bool):
@@ -98,7 +100,7 @@ def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward
     (and can be captured in a HIP graph).  Returns a dict of the step's observable results."""
     B, T, d = inp.x.shape
     key_len, K = inp.key_len_dev(rate)
-    scores = scorer(inp.x).squeeze(-1).float()
+    scores = scorer(inp.x, inp.valid).squeeze(-1).float()
     # rows: frames that can receive a score gradient = the B*K selected slots (pad slots get exact zeros)
     nmask, idx, sg, table, pos, rows = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K, want_rows=True)
     scorer.set_active_rows(rows)
@@ -117,8 +119,10 @@ def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, back
     B, T, d = inp.x.shape
     if cap is None:
         cap = int(max(inp.target_lengths)) + 2
-    scorer.set_active_rows(None)                       # every valid frame gets the quantity-loss gradient
-    scores = scorer(inp.x.detach()).squeeze(-1).float()                                  # w2v_simul.py:410-411
+    # every valid frame gets the quantity-loss gradient; pad frames get none (alphas = sigmoid(s) * mask), and with
+    # inp.valid the scorer's backward runs over the valid frames only
+    scorer.set_active_rows(None)
+    scores = scorer(inp.x.detach(), inp.valid).squeeze(-1).float()                       # w2v_simul.py:410-411
     alphas, qloss = ops.cif_quantity(scores, inp.target_lengths_dev, lengths=inp.lengths_dev)  # :419-424
     resized = ops.cif_resize(alphas, inp.target_lengths_dev)                            # :425
     idx, nmask, counts, mx, _ = ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap)  # :426

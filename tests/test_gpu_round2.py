@@ -396,7 +396,9 @@ def test_nugget_step_simul_gradients_vs_oracle(ops, ilk):
     ref = orc.nugget_step_simul(xr, sr, lengths, tl, ilk, w1r, b1, w2, b2, qs, [(cpu(a), cpu(b)) for a, b in inp.kv_scales],
                                 [cpu(g) for g in inp.gs], fires=fires)
     assert fires[1].shape[1] == K
-    np.testing.assert_allclose(out["scores"].detach().cpu().numpy(), ref["scores"].detach().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out["scores"].detach().cpu().numpy()[mask], ref["scores"].detach().numpy()[mask],
+                               rtol=2e-3, atol=2e-3)
+    assert (out["scores"].detach().cpu().numpy()[~mask] == 0).all()          # ragged scorer: pad frames are 0
     np.testing.assert_allclose(out["alphas"].detach().cpu().numpy(), ref["alphas"].detach().numpy(), rtol=2e-3, atol=1e-4)
     np.testing.assert_allclose(out["resized"].detach().cpu().numpy(), ref["resized"].detach().numpy(), rtol=2e-3, atol=1e-4)
     assert abs(out["quantity_loss"].item() - ref["quantity_loss"].item()) <= 5e-3 * abs(ref["quantity_loss"].item()) + 1e-4
@@ -709,3 +711,45 @@ def test_streaming_segmenter_matches_offline(ops):
         assert torch.equal(mem[b, :n], mem_off[b, :n])
         assert torch.equal(msc[b, :n], sg[b, :n])
     assert bool(seg.finished().all())
+
+
+# ------------------------------------------------------------------------------------------------ ragged scorer
+def test_ragged_scorer_equals_dense_on_valid_frames(ops):
+    """star_scorer_fwd_ragged skips row tiles that hold padding only and writes 0 at pad frames: scores at valid frames
+    and every gradient are bit-identical to the dense call with the same cotangent (zero at pad frames), for a dense
+    backward (quantity-loss-like) and for a backward with an active-row hint."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(4)
+    B, T, d = 7, 700, 256
+    lengths = [700, 13, 300, 0, 699, 257, 512]
+    valid = ops.ValidFrames(lengths, T, DEV)
+    mask = torch.from_numpy(lmask(lengths, T)).to(DEV)
+    assert valid.n_valid == sum(lengths) and valid.n_live < (B * T + 255) // 256
+    sc = NuggetScorer(d).to(DEV)
+    x = torch.randn(B, T, d, device=DEV).to(torch.bfloat16)
+    g = torch.randn(B, T, device=DEV) * mask
+    res = []
+    for v in (None, valid):
+        for hinted in (False, True):
+            xr = x.clone().requires_grad_()
+            sc.zero_grad()
+            s = sc(xr, v).squeeze(-1)
+            gg = g.clone()
+            if hinted:
+                keep = torch.zeros_like(mask)
+                keep[:, ::5] = True
+                gg = gg * keep
+                rows = (keep & mask).view(-1).nonzero().view(-1).to(torch.int32)
+                sc.set_active_rows(rows)
+            s.backward(gg)
+            res.append((s.detach().clone(), xr.grad.clone(), [p.grad.clone() for p in sc.parameters()]))
+    for exact, (a, b) in ((False, (res[0], res[2])), (True, (res[1], res[3]))):
+        assert torch.equal(a[0][mask], b[0][mask]) and (b[0][~mask] == 0).all()
+        assert torch.equal(a[1], b[1])
+        for pa, pb in zip(a[2], b[2]):
+            if exact:                      # same row list -> same kernels on the same operands
+                assert torch.equal(pa, pb)
+            else:                          # all B*T rows against the valid rows: other tiles, other summation order
+                close(pb, pa, "scorer parameter gradient", 1e-5)
+    with pytest.raises(ValueError):
+        sc(x[:, :100], valid)
