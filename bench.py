@@ -317,19 +317,33 @@ def main():
         # the training forward: it also emits the ReLU sign bits the backward consumes
         bits = torch.empty(_lib.lib().star_scorer_relu_bits_bytes(N, d), dtype=torch.uint8, device=dev)
 
+        valid = inp.valid                          # ragged batch: the launch the step makes skips all-padding row tiles
+
         def launch():
-            _lib.check(_lib.lib().star_scorer_fwd(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
-                                                  b2f.data_ptr(), N, d, sc.data_ptr(), bits.data_ptr(), ws.data_ptr(),
-                                                  wsb, _lib.stream_ptr()), "star_scorer_fwd")
+            if valid is None:
+                _lib.check(_lib.lib().star_scorer_fwd(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
+                                                      b2f.data_ptr(), N, d, sc.data_ptr(), bits.data_ptr(), ws.data_ptr(),
+                                                      wsb, _lib.stream_ptr()), "star_scorer_fwd")
+            else:
+                _lib.check(_lib.lib().star_scorer_fwd_ragged(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
+                                                             b2f.data_ptr(), valid.lengths.data_ptr(), B, T, d,
+                                                             valid.live_tiles.data_ptr(), valid.n_live, sc.data_ptr(),
+                                                             bits.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()),
+                           "star_scorer_fwd_ragged")
         legs_stream = torch.cuda.Stream()         # graph capture needs a non-default stream
         legs_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(legs_stream)
         avg_us = event_time_us(launch, iters=max(args.steps, 10), graph=False)
-        flops = float(N) * (2.0 * d * d + 2.0 * d)
+        # algorithmic work: the valid frames only (a ragged launch also computes the pad frames of its partly filled tiles)
+        flops = float(N if valid is None else valid.n_valid) * (2.0 * d * d + 2.0 * d)
         ach = flops / (avg_us * 1e-6) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_SCORE> (+ scorer_finish_kernel)", "achieved": round(ach, 2),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(N, d), "avg_us": round(avg_us, 2), "flop_per_launch": flops}
+                    "traffic": pmc_traffic(N, d) if valid is None else None, "avg_us": round(avg_us, 2),
+                    "flop_per_launch": flops,
+                    "launch": "star_scorer_fwd" if valid is None else
+                    "star_scorer_fwd_ragged: %d of %d row tiles computed, %d valid frames" % (valid.n_live, (N + 255) // 256,
+                                                                                          valid.n_valid)}
         if not args.no_roofline_all:
             roofline_all = roofline_legs(ops, scorer, inp, wl, rate, dev, roofline)
         torch.cuda.synchronize()

@@ -19,12 +19,16 @@ if a.lib:
 from star_amd import ops
 dev = "cuda:0"
 torch.manual_seed(0)
+# everything runs on one non-default stream: a graph capture needs one, and autograd runs a backward node on the stream
+# its forward ran on, so forwards built outside the capture must live on the capture stream too
+_stream = torch.cuda.Stream()
+torch.cuda.set_stream(_stream)
 
 def timeit(name, fn, flops=None, bytes_=None):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
         for _ in range(a.iters): fn()
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
