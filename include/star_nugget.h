@@ -101,6 +101,24 @@ int star_diag_fanout_fwd(const void* mem, const void* scales, int J, int64_t R, 
 int star_diag_fanout_bwd(const void* const* grads_host, int J, const void* scales, int64_t R, int d, void* dmem,
                          void* stream);
 
+/* ---------------------------------------------------------------- f-3 (second half): gather at the output of the
+ * semantic encoder.  The reference normalises all T frames with the encoder's final LayerNorm (ln_f,
+ * my_transformer.py:945) and then keeps the nugget rows (w2v_asr.py:566-567, w2v_simul.py:446-447); LayerNorm is
+ * row-wise, so the rows are gathered first and only they are normalised:
+ *   out[b,j,:] = LayerNorm(src[b, idx[b,j], :]) * gamma + beta        (idx as in star_gather_rows_fwd: -1 = last frame)
+ *   src [B,T,d] and out [B,K,d] in dtype (STAR_DT_BF16 / STAR_DT_F32), gamma / beta [d] fp32, statistics in fp32
+ *   mean, rstd [B,K] fp32: outputs of the forward, inputs of the backward.  d % 8 == 0, d <= 4096 (backward: 1536).
+ * Backward: drows [B,K,d] (dtype) = LayerNorm backward of every gathered row; pass it to star_gather_rows_bwd to get
+ * d src (duplicates summed, every row written once).  dgamma, dbeta [d] fp32 (fixed summation order). */
+int star_gather_layernorm_fwd(const void* src, int dtype, const int64_t* idx, const float* gamma,
+                              const float* beta, float eps, int B, int T, int K, int d, void* out, float* mean,
+                              float* rstd, void* stream);
+size_t star_gather_layernorm_bwd_workspace(int B, int K, int d);
+int star_gather_layernorm_bwd(const void* src, int dtype, const int64_t* idx, const float* gamma,
+                              const float* mean, const float* rstd, const void* dout, int B, int T, int K,
+                              int d, void* drows, float* dgamma, float* dbeta, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- a5: CIF quantity loss
  * Replaces w2v_simul.py:419-424.  alphas = sigmoid(scores)*mask; diff_b = sum_t alphas/thr - L_b;
  * loss = mean_b diff_b^2.  attn_mask/lengths as in star_topk_select.  target_lengths [B] int32.

@@ -121,6 +121,15 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return src[b, idx]
 
 
+def gather_layernorm(hidden: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                     eps: float = 1e-5) -> torch.Tensor:
+    """The semantic encoder's final LayerNorm over every frame (my_transformer.py:945) followed by the nugget row
+    gather (w2v_asr.py:566-567): ln_f(hidden)[arange(B)[:,None], idx], in the reference's order (normalise all T
+    frames, then index).  Differentiable."""
+    y = torch.nn.functional.layer_norm(hidden, (hidden.shape[-1],), weight, bias, eps)
+    return gather_rows(y, idx)
+
+
 # --------------------------------------------------------------------------- a5
 def quantity_loss(scores: torch.Tensor, attn_mask: torch.Tensor,
                   target_lengths: torch.Tensor, threshold: float = 1.0):

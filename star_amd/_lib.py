@@ -53,6 +53,9 @@ SIGNATURES = {
     "star_cif_quantity_bwd": (_I, [_P, _P, _P, _F, _I, _I, _I, _P, _P]),
     "star_cif_resize": (_I, [_P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "star_cif_resize_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "star_gather_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, C.c_float, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "star_gather_layernorm_bwd_workspace": (_SZ, [_I, _I, _I]),
+    "star_gather_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_fire_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["error.cpp", "select.hip", "gather.hip", "cif.hip", "cifagg.hip", "typeembed.hip", "gemm.hip", "xattn.hip"]
+SOURCES = ["error.cpp", "select.hip", "gather.hip", "cif.hip", "cifagg.hip", "typeembed.hip", "gatherln.hip", "gemm.hip", "xattn.hip"]
 LIB = os.path.join(HERE, "libstar_nugget.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file extras (STAR_XATTN_FLAGS etc. override for experiments)

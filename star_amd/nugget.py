@@ -59,6 +59,15 @@ def gather_nuggets(semantic_repr: torch.Tensor, nugget_indices: torch.Tensor) ->
     return ops.gather_rows(semantic_repr, nugget_indices)
 
 
+def gather_nuggets_layernorm(hidden: torch.Tensor, nugget_indices: torch.Tensor, ln_f: nn.LayerNorm) -> torch.Tensor:
+    """ln_f(hidden)[torch.arange(B)[:, None], nugget_indices] for the semantic encoder's final LayerNorm
+    (my_transformer.py:945, then w2v_asr.py:566-567): call the encoder without its ln_f and pass the
+    un-normalised last hidden state here -- only the nugget rows are normalised and written."""
+    if tuple(ln_f.normalized_shape) != (hidden.shape[-1],) or ln_f.weight is None or ln_f.bias is None:
+        raise ValueError("gather_nuggets_layernorm: ln_f must be an affine LayerNorm over the last dimension")
+    return ops.gather_layernorm(hidden, nugget_indices, ln_f.weight, ln_f.bias, ln_f.eps)
+
+
 # ------------------------------------------------------------------------------------------ a2, a3, a6, a7
 class NuggetOpsMixin:
     """Methods with the reference's names and signatures; expects `self.nugget_compress_rate` and

@@ -177,6 +177,64 @@ def gather_rows(src, idx):
     return _GatherRows.apply(src, idx.to(torch.int64))
 
 
+class _GatherLayerNorm(torch.autograd.Function):
+    """ln_f(hidden)[arange(B)[:,None], idx] computed as ln_f(hidden[idx]) (my_transformer.py:945 + w2v_asr.py:566-567):
+    only the B*K gathered rows are normalised."""
+
+    @staticmethod
+    def forward(ctx, src, idx, weight, bias, eps):
+        ctx.set_materialize_grads(False)
+        s3 = src.detach().contiguous()
+        B, T, d = s3.shape
+        K = idx.shape[1]
+        idx = idx.contiguous()
+        gm = weight.detach().to(torch.float32).contiguous()
+        bt = bias.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, K, d), dtype=s3.dtype, device=s3.device)
+        mean = torch.empty((B, K), dtype=torch.float32, device=s3.device)
+        rstd = torch.empty((B, K), dtype=torch.float32, device=s3.device)
+        dt = DT_BF16 if s3.dtype == torch.bfloat16 else DT_F32
+        check(lib().star_gather_layernorm_fwd(ptr(s3), dt, ptr(idx), ptr(gm), ptr(bt), float(eps), B, T, K, d, ptr(out),
+                                              ptr(mean), ptr(rstd), stream_ptr()), "star_gather_layernorm_fwd")
+        ctx.save_for_backward(s3, idx, gm, mean, rstd)
+        ctx.dt = dt
+        ctx.wdtypes = (weight.dtype, bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None
+        s3, idx, gm, mean, rstd = ctx.saved_tensors
+        B, T, d = s3.shape
+        K = idx.shape[1]
+        g3 = g.to(s3.dtype).contiguous()
+        drows = torch.empty((B, K, d), dtype=s3.dtype, device=s3.device)
+        dgamma = torch.empty((d,), dtype=torch.float32, device=s3.device)
+        dbeta = torch.empty((d,), dtype=torch.float32, device=s3.device)
+        wsb = lib().star_gather_layernorm_bwd_workspace(B, K, d)
+        ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=s3.device)
+        check(lib().star_gather_layernorm_bwd(ptr(s3), ctx.dt, ptr(idx), ptr(gm), ptr(mean), ptr(rstd), ptr(g3), B, T, K, d,
+                                              ptr(drows), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, stream_ptr()),
+              "star_gather_layernorm_bwd")
+        dsrc = None
+        if ctx.needs_input_grad[0]:
+            dsrc = torch.empty((B, T, d), dtype=s3.dtype, device=s3.device)
+            check(lib().star_gather_rows_bwd(ptr(drows), ptr(idx), ptr(dsrc), B, T, K, d, ctx.dt, stream_ptr()),
+                  "star_gather_rows_bwd")
+        return dsrc, None, dgamma.to(ctx.wdtypes[0]), dbeta.to(ctx.wdtypes[1]), None
+
+
+def gather_layernorm(src, idx, weight, bias, eps: float = 1e-5):
+    """LayerNorm(src)[arange(B)[:,None], idx] for src [B,T,d] (bf16 / fp32) without normalising the frames that are not
+    gathered: the semantic encoder's ln_f (my_transformer.py:945) followed by the nugget row gather
+    (w2v_asr.py:566-567, w2v_simul.py:446-447).  idx -1 addresses the last frame.  Differentiable in src, weight, bias."""
+    _need_cuda(src, idx, weight, bias)
+    if src.dim() != 3 or src.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"gather_layernorm: src must be [B,T,d] bf16 / fp32, got {tuple(src.shape)} {src.dtype}")
+    return _GatherLayerNorm.apply(src, idx.to(torch.int64), weight, bias, float(eps))
+
+
 class _DiagFanout(torch.autograd.Function):
     """Harness stand-in for the per-layer c_attn projection: K_l/V_l = mem * scale_j (one pass fwd, one bwd)."""
 

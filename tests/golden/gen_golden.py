@@ -493,9 +493,39 @@ def gen_xattn_drop():
              keep=keep, drop_p=np.float32(p), gout=gout, o=o, p=pw, dq=q.grad, dk=k.grad, dv=v.grad, dscores=sc.grad)
 
 
+def gen_gather_ln():
+    """The tail of the reference's semantic encoder and the gather that follows it: `hidden_states = self.ln_f(
+    hidden_states)` of MyGPT2Model.forward (my_transformer.py:945, ln_f = nn.LayerNorm(n_embd, eps=layer_norm_epsilon),
+    :765) on a real MyGPT2Model instance, then `semantic_repr[torch.arange(B).unsqueeze(1), nugget_indices]`
+    (w2v_asr.py:566-567) with the reference's own compression picking the rows (pad slots included); forward and the
+    gradients into the hidden states and the LayerNorm parameters."""
+    from transformers import GPT2Config
+    asr = w2v_asr.W2VASRModel
+    for name, (B, T, d, lengths, rate, seed) in {"a": (3, 50, 64, [50, 41, 7], 4, 41),
+                                                 "b": (2, 37, 256, [37, 20], 2, 42)}.items():
+        g = torch.Generator().manual_seed(seed)
+        cfg = GPT2Config(n_embd=d, vocab_size=4, n_positions=64, n_layer=1, n_head=4, add_cross_attention=False)
+        model = my_transformer.MyGPT2Model(cfg)
+        ln_f = model.ln_f
+        with torch.no_grad():
+            ln_f.weight.copy_(1.0 + 0.3 * torch.randn(d, generator=g))
+            ln_f.bias.copy_(0.2 * torch.randn(d, generator=g))
+        hidden = (torch.randn(B, T, d, generator=g) * 1.7 + 0.4).requires_grad_()
+        scores = torch.randn(B, T, generator=g)
+        mask = len_mask(lengths, T)
+        ns = SimpleNamespace(nugget_compress_rate=rate, nugget_model=None)
+        nmask, idx, _ = asr.apply_nugget_compression(ns, hidden, mask, nugget_scores=scores)
+        y = ln_f(hidden)
+        out = y[torch.arange(B).unsqueeze(1), idx]
+        gout = torch.randn(out.shape, generator=g)
+        (out * gout).sum().backward()
+        save(f"gatherln_{name}", hidden=hidden, idx=idx, weight=ln_f.weight, bias=ln_f.bias, eps=np.float64(ln_f.eps),
+             out=out, gout=gout, dhidden=hidden.grad, dweight=ln_f.weight.grad, dbias=ln_f.bias.grad)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed, gen_resize_grad,
-               gen_valid_indices, gen_xattn_drop):
+               gen_valid_indices, gen_xattn_drop, gen_gather_ln):
         if not only or fn.__name__ in only:
             fn()

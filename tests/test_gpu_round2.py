@@ -753,3 +753,56 @@ def test_ragged_scorer_equals_dense_on_valid_frames(ops):
                 close(pb, pa, "scorer parameter gradient", 1e-5)
     with pytest.raises(ValueError):
         sc(x[:, :100], valid)
+
+
+# ------------------------------------------------------------------------------------------------ f-3, second half
+@pytest.mark.parametrize("name", ["gatherln_a", "gatherln_b"])
+def test_gather_layernorm_golden_gpu(ops, name):
+    """ln_f(hidden)[idx] computed as ln_f(hidden[idx]) against the reference call site (fp32: rtol 1e-5; the row
+    statistics are two-pass fp32, torch's are Welford)."""
+    g = load(name)
+    h = dev(g["hidden"]).requires_grad_()
+    w = dev(g["weight"]).requires_grad_()
+    b = dev(g["bias"]).requires_grad_()
+    out = ops.gather_layernorm(h, dev(g["idx"]), w, b, float(g["eps"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
+    (out * dev(g["gout"])).sum().backward()
+    np.testing.assert_allclose(h.grad.cpu().numpy(), g["dhidden"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), g["dweight"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g["dbias"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,K,d,dtype", [(32, 1500, 375, 1024, torch.bfloat16), (3, 70, 90, 768, torch.float32),
+                                            (2, 33, 5, 8, torch.float32), (4, 129, 40, 1536, torch.bfloat16)])
+def test_gather_layernorm_random_vs_oracle(ops, B, T, K, d, dtype):
+    """Random rows incl. -1 pads and duplicate indices (their gradients add up in d hidden), K > T, the configs[1] size;
+    bf16 inputs: the oracle runs in fp32 on the bf16-rounded inputs, outputs compared at bf16 resolution."""
+    from star_amd.nugget import gather_nuggets_layernorm
+    rng = np.random.default_rng(B * 1000 + d)
+    idx = np.sort(rng.integers(0, T, size=(B, K)), axis=1)
+    idx[:, -max(K // 8, 1):] = -1
+    h32 = (torch.randn(B, T, d) * 2 + 0.5).to(dtype).float()
+    ln = torch.nn.LayerNorm(d, eps=1e-5)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(d))
+        ln.bias.copy_(0.2 * torch.randn(d))
+    gout32 = torch.randn(B, K, d).to(dtype).float()
+    hr = h32.clone().requires_grad_()
+    wr, br = ln.weight.detach().clone().requires_grad_(), ln.bias.detach().clone().requires_grad_()
+    ref = orc.gather_layernorm(hr, torch.from_numpy(idx), wr, br, 1e-5)
+    (ref * gout32).sum().backward()
+    lnd = torch.nn.LayerNorm(d, eps=1e-5).to(DEV)
+    lnd.load_state_dict(ln.state_dict())
+    hd = h32.to(dtype).to(DEV).requires_grad_()
+    out = gather_nuggets_layernorm(hd, dev(idx), lnd)
+    assert out.dtype == dtype and out.shape == (B, K, d)
+    (out.float() * gout32.to(DEV)).sum().backward()
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    close(out, ref, "out", tol)
+    close(hd.grad, hr.grad, "d hidden", 2 * tol)
+    close(lnd.weight.grad, wr.grad, "d weight", 2 * tol if dtype == torch.bfloat16 else 1e-4)
+    close(lnd.bias.grad, br.grad, "d bias", 2 * tol if dtype == torch.bfloat16 else 1e-4)
+    never = np.ones((B, T), dtype=bool)
+    for bb in range(B):
+        never[bb, np.where(idx[bb] < 0, T - 1, idx[bb])] = False
+    assert (hd.grad.float().cpu().numpy()[never] == 0).all()          # frames that were not gathered: exact zeros

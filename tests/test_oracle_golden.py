@@ -298,3 +298,20 @@ def test_dropout_keep_mask_statistics():
     m4, _ = orc.dropout_keep_mask(1234, 7, 3, 4, 64, 200, p)
     assert np.array_equal(m, m4)
     assert orc.dropout_keep_mask(1, 2, 1, 1, 4, 4, 0.0)[0].all()
+
+
+# ------------------------------------------------------------------ 8f-3, second half: final LayerNorm + nugget row gather
+@pytest.mark.parametrize("name", ["gatherln_a", "gatherln_b"])
+def test_gather_layernorm_golden(name):
+    """oracle ln_f + gather against the reference's MyGPT2Model.ln_f (my_transformer.py:945) and the row gather of
+    w2v_asr.py:566-567, forward and all three gradients."""
+    g = load(name)
+    h = torch.from_numpy(g["hidden"]).requires_grad_()
+    w = torch.from_numpy(g["weight"]).requires_grad_()
+    b = torch.from_numpy(g["bias"]).requires_grad_()
+    out = orc.gather_layernorm(h, torch.from_numpy(g["idx"]), w, b, float(g["eps"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    (out * torch.from_numpy(g["gout"])).sum().backward()
+    np.testing.assert_allclose(h.grad.numpy(), g["dhidden"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.grad.numpy(), g["dweight"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b.grad.numpy(), g["dbias"], rtol=1e-5, atol=1e-6)

@@ -8,6 +8,6 @@ mkdir -p build/stamp
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value"
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -DSTAR_XA_STAMP "$@" -c xattn.hip -o build/stamp/xattn$TAG.o
 OBJS="build/stamp/xattn$TAG.o"
-for f in error select gather cif cifagg typeembed gemm; do OBJS="$OBJS build/$f.o"; done
+for f in error select gather cif cifagg typeembed gatherln gemm; do OBJS="$OBJS build/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/libstar_stamp$TAG.so $OBJS
 echo built tools/libstar_stamp$TAG.so
