@@ -17,7 +17,8 @@ For N > 1 the step carries the gradient all-reduces of SURVEY.md section 8e over
 gradient buffer (1.05 M values) and the decoder's cross-attention parameter gradients (nl x (4 d^2 + 6 d) = 16.8 M
 values; the decoder weights themselves are outside the hot path, so that buffer is payload of the right size).  The
 second buffer is reduced on a side stream as soon as the attention backward kernels are done, beside the gather and
-scorer backward.  The step is captured in two HIP graphs (no host sync inside) and replayed.
+scorer backward.  The step is captured in HIP graphs (no host sync inside; one graph at N = 1, two around the
+start of the side-stream all-reduce for N > 1) and replayed.
 Prints ONE JSON line on rank 0 (fields: DESIGN.md section 5).
 """
 import argparse
@@ -244,8 +245,8 @@ def main():
     torch.cuda.synchronize()
     graph_a = graph_b = None
     if not args.no_graph:
-        # two graphs: forward + attention backward | gather / scorer backward.  For N > 1 the decoder-side
-        # all-reduce starts between them; at N = 1 they replay back to back.
+        # N > 1: two graphs, forward + attention backward | gather / scorer backward, with the start of the decoder-side
+        # all-reduce between them; N = 1: one graph.
         reset_grads()
         graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_a):
@@ -253,9 +254,12 @@ def main():
                 allreduce.zero()               # part of the replayed step: backward accumulates into the buffer
             out_c = forward()
             dmem_c, dsg_c = attention_backward(out_c, inp)
-        graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_b, pool=graph_a.pool()):
-            rest(out_c, dmem_c, dsg_c)
+            if world == 1:                     # nothing happens between the halves: one graph, no replay gap
+                rest(out_c, dmem_c, dsg_c)
+        if world > 1:
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+                rest(out_c, dmem_c, dsg_c)
 
     def run_step(with_allreduce=True):
         if graph_a is not None:
@@ -268,7 +272,7 @@ def main():
             decoder_side.start(world)            # side stream: runs beside the gather / scorer backward
         if graph_b is not None:
             graph_b.replay()
-        else:
+        elif graph_a is None:
             rest(out, dmem, dsg)
         if world > 1 and with_allreduce:
             allreduce(world)
