@@ -806,3 +806,36 @@ def test_gather_layernorm_random_vs_oracle(ops, B, T, K, d, dtype):
     for bb in range(B):
         never[bb, np.where(idx[bb] < 0, T - 1, idx[bb])] = False
     assert (hd.grad.float().cpu().numpy()[never] == 0).all()          # frames that were not gathered: exact zeros
+
+
+def test_fire_scan_many_utterances_and_small_cap(ops):
+    """Huge batches put several utterances into one workgroup of the scan (one serial lane each, both recurrences side
+    by side in one wave); a cap below the fire count drops the late fires but still counts them."""
+    rng = np.random.default_rng(11)
+    B, T = 4200, 48
+    a = (rng.random((B, T)) * 0.6).astype(np.float32)
+    a[::7] *= 3.0                                   # every seventh row takes the generic chain (weights above 1)
+    lengths = rng.integers(1, T + 1, size=B)
+    mask = lmask(lengths, T)
+    o_mask, o_idx, _ = orc.fire_scan(a, mask, with_block_mask=False)
+    ln = torch.from_numpy(lengths.astype(np.int32)).to(DEV)
+    idx, m, cnt, mx, _ = ops.cif_fire_scan(dev(a), lengths=ln, cap=T)
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    np.testing.assert_array_equal(cnt, o_mask.sum(1))
+    kf = o_idx.shape[1]
+    np.testing.assert_array_equal(idx[:, :kf], o_idx)
+    assert int(mx.item()) == kf
+    # the same rows in two chunks through the streaming step
+    st = ops.FireState(B, DEV)
+    i1, c1, _ = ops.cif_fire_step(dev(a[:, :20].copy()), ln, st, cap=20)
+    i2, c2, _ = ops.cif_fire_step(dev(a[:, 20:].copy()), ln, st, cap=T - 20)
+    np.testing.assert_array_equal((c1 + c2).cpu().numpy(), cnt)
+    both = torch.cat([i1, i2], 1).cpu().numpy()
+    for b in range(0, B, 97):
+        got = both[b][both[b] >= 0]
+        np.testing.assert_array_equal(got, o_idx[b][o_idx[b] >= 0])
+    # cap smaller than the number of fires
+    cap = 3
+    idx3, m3, cnt3, _, _ = ops.cif_fire_scan(dev(a), lengths=ln, cap=cap)
+    np.testing.assert_array_equal(cnt3.cpu().numpy(), cnt)
+    np.testing.assert_array_equal(idx3.cpu().numpy()[:, :min(cap, kf)], o_idx[:, :cap])
