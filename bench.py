@@ -439,6 +439,9 @@ def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg):
         leg("resize", "cif_resize_kernel", us, bytes_=8.0 * B * T)
         us = event_time_us(lambda: ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap))
         leg("fire scan", "cif_fire_scan_kernel", us, bytes_=4.0 * B * T + 9.0 * B * cap)
+        us = event_time_us(lambda: ops.cif_segment(scores, inp.target_lengths_dev, inp.lengths_dev, cap=cap))
+        leg("segmenter as the step runs it: quantity + resize + fire scan + score gather + type table, one launch",
+            "cif_segment_kernel (+ cif_quantity_loss_kernel)", us, bytes_=4.0 * B * T * 3 + 8.0 * B * T + 21.0 * B * cap)
         idx, nmask, counts, _, _ = ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap)
         key_len, K = counts, cap
         ilk = 2 if wl["ilk"] else -1

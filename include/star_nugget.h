@@ -160,6 +160,20 @@ int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask, const int3
                        const float* scores, int B, int T, int cap, int64_t* idx_out,
                        uint8_t* mask_out, int32_t* counts, int32_t* max_count,
                        float* scores_gather, void* stream);
+/* ---------------------------------------------------------------- a5 + a6 + a7 + a3 in one launch
+ * The segmenter of the simultaneous path as the reference chains it (w2v_simul.py:419-431): alphas = sigmoid(scores)
+ * * mask and the quantity loss, resize(alphas, target_lengths), apply_threshold_yield_nugget on the resized weights,
+ * nugget_scores = scores[b, idx] and add_nugget_type_embedding's table -- one workgroup per utterance keeps the row
+ * in LDS through all stages.  Outputs are bit-identical to star_cif_quantity_fwd -> star_cif_resize ->
+ * star_cif_fire_scan (with scores) -> star_nugget_type_table.  Prefix masks only (lengths [B] int32, unclamped as in
+ * star_cif_fire_scan).  type_table [B,T] int64 and positions [B,cap] int64 may be NULL; max_count may be NULL.
+ * Gradients: star_cif_quantity_bwd for the loss, star_gather_rows_bwd (d = 1) for scores_gather. */
+int star_cif_segment(const float* scores, const int32_t* lengths, const int32_t* target_lengths,
+                     float threshold, int max_rounds, int B, int T, int cap, float* alphas, float* diff,
+                     float* loss, float* resized, int32_t* fixups_out, int64_t* idx_out, uint8_t* mask_out,
+                     int32_t* counts, int32_t* max_count, float* scores_gather, int64_t* type_table,
+                     int64_t* positions, void* stream);
+
 /* ---------------------------------------------------------------- f4: streaming fire decision
  * The same recurrence fed one chunk of frames at a time (online fire decision; the
  * reference runs apply_threshold_yield_nugget, w2v_simul.py:376-403, on whole utterances only, so this entry point

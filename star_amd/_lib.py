@@ -57,6 +57,7 @@ SIGNATURES = {
     "star_gather_layernorm_bwd_workspace": (_SZ, [_I, _I, _I]),
     "star_gather_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "star_cif_segment": (_I, [_P, _P, _P, _F, _I, _I, _I, _I] + [_P] * 12 + [_P]),
     "star_cif_fire_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

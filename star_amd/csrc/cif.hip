@@ -318,6 +318,146 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
     if (state_pos && tid < nrows) state_pos[b0 + tid] += T;
 }
 
+// ------------------------------------------------------------------------------------------ a5 + a6 + a7 + a3 fused
+// The simultaneous path's segmenter in ONE launch (w2v_simul.py:419-431): alphas = sigmoid(scores) * mask and the
+// quantity-loss difference (a5), resize (a6), the fire scan with its score gather (a7) and the nugget type table (a3),
+// one workgroup per utterance with the row resident in LDS from the first step to the last.  Every stage is the code
+// of the stand-alone kernel above (same thread partition of every sum, same recurrence), so all outputs are
+// bit-identical to cif_quantity_fwd -> cif_resize -> cif_fire_scan -> gather -> type table; it saves five launches of
+// 4-9 us each on the critical path of the step.  Prefix masks only (lengths).
+__global__ __launch_bounds__(256) void cif_segment_kernel(
+    const float* __restrict__ scores, const int32_t* __restrict__ lengths, const int32_t* __restrict__ target_lengths,
+    float threshold, int max_rounds, int T, int cap, float* __restrict__ alphas, float* __restrict__ diff,
+    float* __restrict__ resized, int32_t* __restrict__ fixups_out, int64_t* __restrict__ idx_out,
+    uint8_t* __restrict__ mask_out, int32_t* __restrict__ counts, int32_t* __restrict__ max_count,
+    float* __restrict__ scores_gather, int64_t* __restrict__ table, int64_t* __restrict__ positions) {
+    extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+    const int pitch = scan_pitch(T), T16 = (T + 15) & ~15;
+    float* row = sg_smem;                          // [pitch] alphas -> resized -> pre-fire integrals
+    float* thr_row = sg_smem + pitch;              // [pitch] per-frame thresholds of the scan
+    uint32_t* snap = (uint32_t*)(sg_smem + 2 * pitch);   // resize: offender snapshot bits
+    __shared__ double red[4];
+    __shared__ int flag, wtot[4], slow;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = lengths[b];                      // unclamped (a length > T: every frame valid, no forced fire)
+    const float* srow = scores + (size_t)b * T;
+    const int nwords = (T + 31) / 32;
+    if (tid == 0) slow = 0;
+
+    // ---- a5: alphas and the quantity difference (cif_quantity_fwd_kernel)
+    double acc = 0.0, acc_r = 0.0;
+    for (int i = tid; i < T; i += CIF_THREADS) {
+        const float a = (i < n) ? 1.0f / (1.0f + expf(-srow[i])) : 0.0f;
+        alphas[(size_t)b * T + i] = a;
+        row[i] = a;
+        acc += (double)(a / threshold);
+        acc_r += (double)a;
+    }
+    for (int i = T + tid; i < T16; i += CIF_THREADS) row[i] = 0.0f;
+    const double tot = block_sum_f64(acc, red);
+    if (tid == 0) diff[b] = (float)tot - (float)target_lengths[b];
+
+    // ---- a6: resize (cif_resize_kernel)
+    const float den = (float)block_sum_f64(acc_r, red);
+    const float scale = __fdiv_rn((float)target_lengths[b], den);
+    for (int i = tid; i < T; i += CIF_THREADS) row[i] = __fmul_rn(row[i], scale);
+    __syncthreads();
+    int nfix = 0;
+    for (int round = 0; round < max_rounds; ++round) {
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        for (int w = tid; w < nwords; w += CIF_THREADS) {
+            uint32_t bits = 0;
+            for (int k = 0; k < 32; ++k) {
+                const int i = w * 32 + k;
+                if (i < T && row[i] > threshold) bits |= 1u << k;
+            }
+            snap[w] = bits;
+            if (bits) flag = 1;
+        }
+        __syncthreads();
+        if (!flag) break;
+        for (int w = 0; w < nwords; ++w) {
+            uint32_t bits = snap[w];
+            while (bits) {
+                const int y = w * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                if (row[y] >= threshold) {
+                    ++nfix;
+                    double s = 0.0, nz = 0.0;
+                    for (int i = tid; i < T; i += CIF_THREADS) {
+                        const float a = row[i];
+                        s += (double)a;
+                        nz += (a != 0.0f) ? 1.0 : 0.0;
+                    }
+                    const float sum = (float)block_sum_f64(s, red);
+                    const float cnt = (float)block_sum_f64(nz, red);
+                    const float mean = __fdiv_rn(__fmul_rn(0.5f, sum), cnt);
+                    for (int i = tid; i < T; i += CIF_THREADS) {
+                        const float a = row[i];
+                        row[i] = __fadd_rn(__fmul_rn(a, 0.5f), (a != 0.0f) ? mean : 0.0f);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (fixups_out && tid == 0) fixups_out[b] = nfix;
+
+    // ---- a7: fire scan on the resized row (cif_fire_scan_kernel, one row per workgroup)
+    bool odd = false;
+    for (int t = tid; t < T16; t += 256) {
+        float v = 0.0f;
+        if (t < T) {
+            const float a = row[t];
+            resized[(size_t)b * T + t] = a;
+            v = (t < n) ? a : a * 0.0f;                    // resized * mask (keeps NaN / inf of the product)
+            odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v <= 1.0f));
+        }
+        row[t] = v;
+        thr_row[t] = t >= T ? __builtin_inff() : ((n == t + 1) ? -__builtin_inff() : 1.0f);
+    }
+    if (odd) slow = 1;
+    __syncthreads();
+    if (tid == 0) {
+        if (!slow) cif_serial_chain_unit(row, T16 >> 4, 0.0f);
+        else cif_serial_chain<true>(row, thr_row, 1.0f, T16 >> 4, 0.0f);
+    }
+    __syncthreads();
+    const int C = (T + 255) / 256;
+    const int lo = min(tid * C, T), hi = min(lo + C, T);
+    int cnt = 0;
+    for (int t = lo; t < hi; ++t) cnt += (row[t] >= thr_row[t]) ? 1 : 0;
+    int nf;
+    int slot = block_excl_scan_256(cnt, wtot, nf);
+    for (int t = lo; t < hi; ++t) {
+        const bool fired = row[t] >= thr_row[t];
+        if (fired) {
+            if (slot < cap) {
+                idx_out[(size_t)b * cap + slot] = t;
+                mask_out[(size_t)b * cap + slot] = 1;
+                scores_gather[(size_t)b * cap + slot] = srow[t];
+                if (positions) positions[(size_t)b * cap + slot] = t;
+            }
+            ++slot;
+        }
+        // ---- a3: the type table marks the frames whose fire has a slot (star_nugget_type_table on idx / mask)
+        if (table) table[(size_t)b * T + t] = (fired && slot <= cap) ? 1 : 0;
+    }
+    if (tid == 0) {
+        counts[b] = nf;
+        if (max_count) atomicMax(max_count, nf);
+    }
+    const float last_score = srow[T - 1];
+    for (int j = nf + tid; j < cap; j += 256) {
+        idx_out[(size_t)b * cap + j] = -1;
+        mask_out[(size_t)b * cap + j] = 0;
+        scores_gather[(size_t)b * cap + j] = last_score;
+        if (positions) positions[(size_t)b * cap + j] = -1;
+    }
+}
+
 // block_attn_mask rows: out[b,i,j] = (prev_fire(i) < j <= i) && valid(i)
 __global__ __launch_bounds__(256) void cif_block_mask_kernel(const int64_t* __restrict__ idx,
                                                              const int32_t* __restrict__ counts,
@@ -453,6 +593,40 @@ extern "C" int star_cif_fire_step(const float* alpha_chunk, const int32_t* lengt
                        (const uint8_t*)nullptr, lengths, score_chunk, B, Tc, cap, R, idx_out, (uint8_t*)nullptr, counts,
                        (int32_t*)nullptr, scores_gather, state_cur, state_pos);
     STAR_LAUNCH_CHECK("star_cif_fire_step");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_segment(const float* scores, const int32_t* lengths, const int32_t* target_lengths,
+                                float threshold, int max_rounds, int B, int T, int cap, float* alphas, float* diff,
+                                float* loss, float* resized, int32_t* fixups_out, int64_t* idx_out, uint8_t* mask_out,
+                                int32_t* counts, int32_t* max_count, float* scores_gather, int64_t* type_table,
+                                int64_t* positions, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(scores && lengths && target_lengths && alphas && diff && loss && resized && idx_out && mask_out && counts &&
+                     scores_gather,
+                 "star_cif_segment: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1 && cap >= 1 && threshold > 0.f, "star_cif_segment: bad shape B=%d T=%d cap=%d", B, T, cap);
+    STAR_REQUIRE(T <= 16384, "star_cif_segment: T=%d exceeds the 16384-frame LDS row limit", T);
+    const size_t smem = (size_t)2 * scan_pitch(T) * 4 + (size_t)((T + 31) / 32) * 4;
+    if (smem > 48 * 1024) {
+        static DevOnce once;
+        if (!reserve_lds_once(once, (const void*)cif_segment_kernel, 152 * 1024)) {
+            set_error("star_cif_segment: cannot reserve LDS");
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    if (max_count) {
+        hipError_t e = hipMemsetAsync(max_count, 0, sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            set_error("star_cif_segment: memset failed: %s", hipGetErrorString(e));
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(cif_segment_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, scores, lengths, target_lengths,
+                       threshold, max_rounds, T, cap, alphas, diff, resized, fixups_out, idx_out, mask_out, counts, max_count,
+                       scores_gather, type_table, positions);
+    hipLaunchKernelGGL(cif_quantity_loss_kernel, dim3(1), dim3(CIF_THREADS), 0, (hipStream_t)stream, diff, B, loss);
+    STAR_LAUNCH_CHECK("star_cif_segment");
     return STAR_OK;
 }
 

@@ -118,6 +118,14 @@ class NuggetOpsMixin:
         kf = max(int(mx.item()), 0)
         return cif[:, :kf], mask[:, :kf].to(torch.float32), idx[:, :kf]
 
+    def segment_nuggets(self, full_nugget_scores, target_lengths, frame_lengths, cap=None):
+        """Optional fast path of lm_nugget_training's segmenter (w2v_simul.py:419-431) when the frame lengths are
+        known as a tensor: quantity loss, resize, apply_threshold_yield_nugget, the score gather and
+        add_nugget_type_embedding in one launch and without a device->host sync.  Returns (alphas, quantity_loss,
+        resized_alphas, nugget_indices [B,cap] (-1 padded), nugget_mask, counts, max_count, nugget_scores,
+        type_ind_table, nugget_index_to_save); cap defaults to T (the reference's width is max_count)."""
+        return ops.cif_segment(full_nugget_scores, target_lengths, frame_lengths, cap=cap)
+
     @staticmethod
     def get_valid_mask_indices(mask: torch.Tensor, padding_value: int = -1):
         """w2v_simul.py:196-220: ascending positions of the True entries, padded; -> (indices, max_valid, n)."""

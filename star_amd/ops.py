@@ -375,6 +375,68 @@ def cif_fire_scan(alphas, attn_mask=None, lengths=None, cap: Optional[int] = Non
     return idx, m.view(torch.bool), counts, mx, sg
 
 
+class _CifSegment(torch.autograd.Function):
+    """Quantity loss + resize + fire scan + score gather + type table of the simultaneous path in one launch
+    (w2v_simul.py:419-431); gradients flow into the scores through the quantity loss and through scores_gather."""
+
+    @staticmethod
+    def forward(ctx, scores, lengths_i32, target_i32, cap, threshold, max_rounds):
+        ctx.set_materialize_grads(False)
+        B, T = scores.shape
+        s = scores.detach().to(torch.float32).contiguous()
+        dev = s.device
+        alphas, resized = torch.empty_like(s), torch.empty_like(s)
+        diff = torch.empty((B,), dtype=torch.float32, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        fix = torch.empty((B,), dtype=torch.int32, device=dev)
+        idx = torch.empty((B, cap), dtype=torch.int64, device=dev)
+        m = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        mx = torch.empty((1,), dtype=torch.int32, device=dev)
+        sg = torch.empty((B, cap), dtype=torch.float32, device=dev)
+        table = torch.empty((B, T), dtype=torch.int64, device=dev)
+        pos = torch.empty((B, cap), dtype=torch.int64, device=dev)
+        check(lib().star_cif_segment(ptr(s), ptr(lengths_i32), ptr(target_i32), float(threshold), int(max_rounds), B, T,
+                                     int(cap), ptr(alphas), ptr(diff), ptr(loss), ptr(resized), ptr(fix), ptr(idx), ptr(m),
+                                     ptr(counts), ptr(mx), ptr(sg), ptr(table), ptr(pos), stream_ptr()),
+              "star_cif_segment")
+        ctx.save_for_backward(alphas, diff, idx)
+        ctx.threshold = float(threshold)
+        ctx.in_dtype = scores.dtype
+        mb = m.view(torch.bool)
+        ctx.mark_non_differentiable(alphas, resized, idx, mb, counts, mx, table, pos)
+        return alphas, loss.reshape(()), resized, idx, mb, counts, mx, sg, table, pos
+
+    @staticmethod
+    def backward(ctx, g_alphas, g_loss, g_resized, g_idx, g_mask, g_counts, g_mx, g_sg, g_table, g_pos):
+        if g_loss is None and g_sg is None:
+            return None, None, None, None, None, None
+        alphas, diff, idx = ctx.saved_tensors
+        B, T = alphas.shape
+        ds = torch.empty_like(alphas)
+        if g_sg is not None:          # scatter of the gathered-score gradient: writes every element of ds
+            gs = g_sg.to(torch.float32).contiguous()
+            check(lib().star_gather_rows_bwd(ptr(gs), ptr(idx), ptr(ds), B, T, idx.shape[1], 1, DT_F32, stream_ptr()),
+                  "star_gather_rows_bwd")
+        if g_loss is not None:
+            gl = g_loss.to(torch.float32).reshape(1).contiguous()
+            check(lib().star_cif_quantity_bwd(ptr(alphas), ptr(diff), ptr(gl), ctx.threshold, B, T,
+                                              1 if g_sg is not None else 0, ptr(ds), stream_ptr()), "star_cif_quantity_bwd")
+        return ds.to(ctx.in_dtype), None, None, None, None, None
+
+
+def cif_segment(scores, target_lengths, lengths, cap: Optional[int] = None, threshold: float = 1.0, max_rounds: int = 10):
+    """The simultaneous path's segmenter (w2v_simul.py:419-431) in one launch, for prefix masks given as lengths:
+    returns (alphas, quantity_loss, resized, idx [B,cap] int64 -1 padded, nugget_mask [B,cap] bool, counts, max_count,
+    nugget_scores = scores[b, idx] (differentiable), type_table [B,T], positions [B,cap]) -- each bit-identical to
+    cif_quantity -> cif_resize -> cif_fire_scan -> gather_rows -> type_table.  No host sync; cap defaults to T."""
+    _need_cuda(scores, target_lengths, lengths)
+    B, T = scores.shape
+    cap = T if cap is None else int(cap)
+    return _CifSegment.apply(scores, lengths.to(torch.int32).contiguous(), target_lengths.to(torch.int32).contiguous(),
+                             cap, float(threshold), int(max_rounds))
+
+
 class FireState:
     """Per-utterance state of the streaming fire decision: the fp32 integrator and the frames consumed so far."""
 
@@ -546,7 +608,8 @@ class ValidFrames:
         for b in range(self.B):
             if ln[b] > 0:
                 live.update(range(int(starts[b] // self.TILE), int((starts[b] + ln[b] - 1) // self.TILE) + 1))
-        self.live_tiles = torch.tensor(sorted(live), dtype=torch.int32, device=device)
+        # (one dummy entry keeps the pointer non-null for a batch without a single valid frame; n_live says 0)
+        self.live_tiles = torch.tensor(sorted(live) or [0], dtype=torch.int32, device=device)
         self.n_live = len(live)
         rows = np.concatenate([starts[b] + np.arange(ln[b]) for b in range(self.B)]) if ln.sum() else np.zeros(0)
         self.rows = torch.from_numpy(rows.astype(np.int32)).to(device)

@@ -123,11 +123,9 @@ def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, back
     # inp.valid the scorer's backward runs over the valid frames only
     scorer.set_active_rows(None)
     scores = scorer(inp.x.detach(), inp.valid).squeeze(-1).float()                       # w2v_simul.py:410-411
-    alphas, qloss = ops.cif_quantity(scores, inp.target_lengths_dev, lengths=inp.lengths_dev)  # :419-424
-    resized = ops.cif_resize(alphas, inp.target_lengths_dev)                            # :425
-    idx, nmask, counts, mx, _ = ops.cif_fire_scan(resized, lengths=inp.lengths_dev, cap=cap)  # :426
-    nugget_scores = ops.gather_rows(scores, idx)                                         # :427
-    table, pos = ops.type_table(idx, nmask, T)                                           # :431
+    # quantity loss (:419-424), resize (:425), fire scan (:426), score gather (:427), type table (:431): one launch
+    alphas, qloss, resized, idx, nmask, counts, mx, nugget_scores, table, pos = ops.cif_segment(
+        scores, inp.target_lengths_dev, inp.lengths_dev, cap=cap)
     mem = ops.gather_rows(inp.s, idx)                                                    # :446-447
     outs, loss = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1, with_loss)
     total = None if loss is None else loss + 0.01 * qloss.detach()                       # :461

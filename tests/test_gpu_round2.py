@@ -753,6 +753,10 @@ def test_ragged_scorer_equals_dense_on_valid_frames(ops):
                 close(pb, pa, "scorer parameter gradient", 1e-5)
     with pytest.raises(ValueError):
         sc(x[:, :100], valid)
+    # a batch without a single valid frame: nothing is computed, every score is 0
+    empty = ops.ValidFrames([0, 0], 300, DEV)
+    with torch.no_grad():
+        assert (sc(x[:2, :300].contiguous(), empty) == 0).all()
 
 
 # ------------------------------------------------------------------------------------------------ f-3, second half
@@ -839,3 +843,62 @@ def test_fire_scan_many_utterances_and_small_cap(ops):
     idx3, m3, cnt3, _, _ = ops.cif_fire_scan(dev(a), lengths=ln, cap=cap)
     np.testing.assert_array_equal(cnt3.cpu().numpy(), cnt)
     np.testing.assert_array_equal(idx3.cpu().numpy()[:, :min(cap, kf)], o_idx[:, :cap])
+
+
+# ------------------------------------------------------------------------------------------------ fused segmenter
+@pytest.mark.parametrize("B,T,frac", [(64, 1500, 0.26), (16, 3000, 1.0), (5, 333, 0.7), (3, 17, 1.0)])
+def test_cif_segment_equals_the_chain_of_kernels(ops, B, T, frac):
+    """star_cif_segment against cif_quantity -> cif_resize -> cif_fire_scan -> gather_rows -> type_table: every output
+    bit-identical, and the score gradient (quantity loss + gathered-score cotangent) equal to autograd's sum of the two."""
+    rng = np.random.default_rng(B + T)
+    lengths = np.maximum((rng.random(B) * frac * T).astype(np.int64), 1)
+    lengths[0] = T
+    tl = np.clip(np.round(0.075 * lengths) + 2, 1, None).astype(np.int32)
+    scores = (torch.randn(B, T) - 2.5).to(DEV)
+    scores[1 % B, : min(5, T)] = 6.0                      # weights near 1 after resize: fix-up rounds
+    ln, tld = dev(lengths.astype(np.int32)), dev(tl)
+    cap = int(tl.max()) + 2
+    s1 = scores.clone().requires_grad_()
+    a1, q1 = ops.cif_quantity(s1, tld, lengths=ln)
+    r1 = ops.cif_resize(a1, tld)
+    i1, m1, c1, x1, _ = ops.cif_fire_scan(r1, lengths=ln, cap=cap)
+    g1 = ops.gather_rows(s1, i1)
+    t1, p1 = ops.type_table(i1, m1, T)
+    s2 = scores.clone().requires_grad_()
+    a2, q2, r2, i2, m2, c2, x2, g2, t2, p2 = ops.cif_segment(s2, tld, ln, cap=cap)
+    for u, v in ((a1, a2), (q1, q2), (r1, r2), (i1, i2), (m1, m2), (c1, c2), (x1, x2), (g1, g2), (t1, t2), (p1, p2)):
+        assert torch.equal(u.detach(), v.detach())
+    gg = torch.randn(B, cap, device=DEV) * m1
+    (0.01 * q1 + (g1 * gg).sum()).backward()
+    (0.01 * q2 + (g2 * gg).sum()).backward()
+    np.testing.assert_allclose(s2.grad.cpu().numpy(), s1.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    # either gradient source alone
+    for use_q, use_g in ((True, False), (False, True)):
+        s3 = scores.clone().requires_grad_()
+        out = ops.cif_segment(s3, tld, ln, cap=cap)
+        s4 = scores.clone().requires_grad_()
+        a4, q4 = ops.cif_quantity(s4, tld, lengths=ln)
+        g4 = ops.gather_rows(s4, i1)
+        ((out[1] if use_q else 0) + ((out[7] * gg).sum() if use_g else 0)).backward()
+        ((q4 if use_q else 0) + ((g4 * gg).sum() if use_g else 0)).backward()
+        assert torch.equal(s3.grad, s4.grad)
+
+
+@pytest.mark.parametrize("name", ["cif_plain", "cif_fixup", "cif_ragged"])
+def test_cif_segment_golden(ops, name):
+    """The fused segmenter on the reference's own vectors (scores, lengths, target lengths of the cif goldens)."""
+    g = load(name)
+    T = g["scores"].shape[1]
+    out = ops.cif_segment(dev(g["scores"].astype(np.float32)), dev(g["target_lengths"].astype(np.int32)),
+                          dev(g["lengths"].astype(np.int32)), cap=T)
+    alphas, qloss, resized, idx, nmask = out[:5]
+    np.testing.assert_allclose(alphas.cpu().numpy(), g["alphas"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(qloss.item(), float(g["quantity_loss"]), rtol=1e-5)
+    kf = g["nugget_indices"].shape[1]
+    if np.array_equal(resized.cpu().numpy(), g["resized"]):           # same resized bits -> same fires, exactly
+        np.testing.assert_array_equal(idx[:, :kf].cpu().numpy(), g["nugget_indices"])
+        np.testing.assert_array_equal(nmask[:, :kf].cpu().numpy(), g["nugget_mask"].astype(bool))
+    else:
+        np.testing.assert_allclose(resized.cpu().numpy(), g["resized"], rtol=2e-5, atol=1e-7)
+    o_mask, o_idx, _ = orc.fire_scan(resized.cpu().numpy(), lmask(g["lengths"], T), with_block_mask=False)
+    np.testing.assert_array_equal(idx[:, :o_idx.shape[1]].cpu().numpy(), o_idx)
