@@ -30,7 +30,10 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
             backend = os.environ.get("STAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # binding the group to its device lets barrier() and the first collective skip the device guess
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 
