@@ -1314,10 +1314,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // without a single barrier: K / V fragments of the NEXT group are prefetched into registers while the current
 // group is being computed (16x16x32 MFMAs, keys on the MFMA column), and the dK / dV stores of the previous
 // group drain behind the next group's arithmetic.  Load, compute and store phases therefore overlap inside a
-// wave instead of relying on co-resident workgroups.
-template <int HD>
+// wave instead of relying on co-resident workgroups.  QR = 256 is the same kernel for targets of up to 256 tokens
+// (133 KB of LDS at HD = 128): configs[3]'s L = 227 then avoids the general dK/dV kernel (29 -> see DESIGN.md).
+template <int HD, int QR = 128>
 struct DkvSmall {
-    static constexpr int QROWS = 128;
+    static constexpr int QROWS = QR;
     static constexpr int ROWB = HD * 2;
     static constexpr int BYTES = 2 * QROWS * ROWB + 2 * QROWS * 4;
     static constexpr int WAVES = 8;
@@ -1329,13 +1330,13 @@ struct DkvSmall {
     }
 };
 
-template <int HD, bool DROP>
+template <int HD, bool DROP, int QR = 128>
 __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V,
     const __bf16* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     const float* __restrict__ bias, const int32_t* __restrict__ key_len, star_xattn_shape s, __bf16* __restrict__ dK,
     __bf16* __restrict__ dV, float* __restrict__ dbias_part) {
-    using C = DkvSmall<HD>;
+    using C = DkvSmall<HD, QR>;
     constexpr int NTH = 512, QROWS = C::QROWS, ROWB = C::ROWB;
     constexpr int KS = HD / 32;       // k-steps of a 16x16x32 MFMA over the head dim
     constexpr int NT = HD / 16;       // 16-wide head-dim tiles of dK^T / dV^T
@@ -2175,18 +2176,26 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
                            (const __bf16*)do_, lse, delta, bias, key_len, *s, (__bf16*)dq);
     }
     if constexpr (HD == 64 || HD == 128) {
-        if (s->L <= DkvSmall<HD>::QROWS && !dkv_gen) {
-            const int smem_s = DkvSmall<HD>::BYTES;
-            XA_RESERVE((xattn_bwd_dkv_small_kernel<HD, DROP>), smem_s, "star_xattn_bwd");
+        if (s->L <= 256 && !dkv_gen) {
             // one workgroup (8 independent waves) per (batch, head); split the key groups over more workgroups
             // only when B*h alone cannot fill the chip
             const int ngroups = cdiv(s->Kn, 16);
             int nch = 1;
             const int64_t bh = (int64_t)s->B * s->h;
             if (bh < 192) nch = (int)min((int64_t)cdiv(ngroups, DkvSmall<HD>::WAVES), (256 + bh - 1) / bh);
-            hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD, DROP>), dim3(nch, s->h, s->B), dim3(512), smem_s, st,
-                               (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
-                               (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+            if (s->L <= 128) {
+                const int smem_s = DkvSmall<HD, 128>::BYTES;
+                XA_RESERVE((xattn_bwd_dkv_small_kernel<HD, DROP, 128>), smem_s, "star_xattn_bwd");
+                hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD, DROP, 128>), dim3(nch, s->h, s->B), dim3(512), smem_s,
+                                   st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
+                                   (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+            } else {
+                const int smem_s = DkvSmall<HD, 256>::BYTES;
+                XA_RESERVE((xattn_bwd_dkv_small_kernel<HD, DROP, 256>), smem_s, "star_xattn_bwd");
+                hipLaunchKernelGGL((xattn_bwd_dkv_small_kernel<HD, DROP, 256>), dim3(nch, s->h, s->B), dim3(512), smem_s,
+                                   st, (const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)do_, lse,
+                                   (const float*)delta, bias, key_len, *s, (__bf16*)dk, (__bf16*)dv, dbias_part);
+            }
             return STAR_OK;
         }
     }

@@ -902,3 +902,39 @@ def test_cif_segment_golden(ops, name):
         np.testing.assert_allclose(resized.cpu().numpy(), g["resized"], rtol=2e-5, atol=1e-7)
     o_mask, o_idx, _ = orc.fire_scan(resized.cpu().numpy(), lmask(g["lengths"], T), with_block_mask=False)
     np.testing.assert_array_equal(idx[:, :o_idx.shape[1]].cpu().numpy(), o_idx)
+
+
+# ------------------------------------------------------------------------------------------------ dK/dV for L <= 256
+@pytest.mark.parametrize("B,h,L,K,hd,ilk,p", [(16, 8, 227, 229, 128, 2, 0.0), (3, 4, 256, 300, 128, -1, 0.0),
+                                              (2, 8, 129, 600, 64, -1, 0.0), (2, 2, 200, 90, 128, 2, 0.2)])
+def test_dkv_small_256_rows_vs_general_kernel(ops, B, h, L, K, hd, ilk, p):
+    """Targets of 129..256 tokens take the barrier-free dK/dV kernel with a 256-row Q / dO block in LDS (configs[3]:
+    L = 227): same results as the general dK/dV kernel (forced through the test override) up to bf16 rounding of the
+    summation order, and both against the fp32 oracle."""
+    g = torch.Generator().manual_seed(L + K)
+    q = torch.randn(B, h, L, hd, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    k = torch.randn(B, h, K, hd, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    v = torch.randn(B, h, K, hd, generator=g).to(torch.bfloat16).to(DEV).requires_grad_()
+    bias = torch.randn(B, K, generator=g).to(DEV).requires_grad_()
+    kl = torch.randint(max(K // 2, 1), K + 1, (B,), generator=g).to(torch.int32).to(DEV)
+    kl[0] = K
+    go = torch.randn(B, h, L, hd, generator=g).to(torch.bfloat16).to(DEV)
+    res = []
+    for mode in (0, 1):
+        ops.test_override(ops.OVR_XA_DKV, mode)
+        try:
+            ops.reset_dropout_state(77)
+            o, _ = ops.xattn(q, k, v, bias=bias, key_len=kl, ilk_diag=ilk, dropout_p=p)
+            res.append(torch.autograd.grad(o, (q, k, v, bias), go))
+        finally:
+            ops.test_override(ops.OVR_XA_DKV, 0)
+    for a, b, what in zip(res[0], res[1], ("dQ", "dK", "dV", "dbias")):
+        close(a, b, what, 1e-2)
+    if p == 0.0:
+        qr, kr, vr = (t.detach().float().cpu().requires_grad_() for t in (q, k, v))
+        br = bias.detach().cpu().requires_grad_()
+        km = torch.arange(K)[None, :] < kl.cpu()[:, None]
+        oref, _ = orc.xattn_core(qr, kr, vr, km, br, ilk >= 0)
+        (oref * go.float().cpu()).sum().backward()
+        for a, b, what in zip(res[0], (qr.grad, kr.grad, vr.grad, br.grad), ("dQ", "dK", "dV", "dbias")):
+            close(a, b, what + " vs oracle", 2e-2)
