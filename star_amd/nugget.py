@@ -159,9 +159,11 @@ class NuggetOpsMixin:
 # ------------------------------------------------------------------------------------------ a8
 def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
                       limit_cross_attn=False, scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
-                      layer_idx=0, key_lengths=None, output_attentions=False, dropout_p=0.0, dropout_rng=None):
+                      layer_idx=0, key_lengths=None, output_attentions=False, dropout_p=0.0, dropout_rng=None,
+                      kv_grad=None):
     """MyGPT2Attention._attn for cross-attention (my_transformer.py:535-603); dropout_p is the probability of
-    `self.attn_dropout` (my_transformer.py:595; pass 0 in eval mode), applied inside the kernels.
+    `self.attn_dropout` (my_transformer.py:595; pass 0 in eval mode), applied inside the kernels.  kv_grad: the
+    gradient slot that came with key / value from share_encoder_kv() (optional).
 
     query [B,h,L,hd], key/value [B,h,K,hd]; attention_mask is the additive [B,1,1,K] encoder mask produced
     by invert_attention_mask (0 / finfo.min); scorer_logits [B,Kb<=K].  Returns (attn_output, attn_weights or
@@ -182,7 +184,7 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
             raise ValueError(f"shared scorer_logits cover {scorer_logits.shape[2]} keys but there are {K}")
         return ops.xattn(query, key, value, bias=scorer_logits, key_len=key_lengths,
                          ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
-                         dropout_p=dropout_p, dropout_rng=dropout_rng)
+                         dropout_p=dropout_p, dropout_rng=dropout_rng, kv_grad=kv_grad)
     if attention_mask is not None:
         if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
             raise ValueError(f"attention_mask must broadcast as [B,1,1,K]; got {tuple(attention_mask.shape)}")
@@ -199,7 +201,7 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
             bias = bias + s
     out, probs = ops.xattn(query, key, value, bias=bias, key_len=key_lengths,
                            ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
-                           dropout_p=dropout_p, dropout_rng=dropout_rng)
+                           dropout_p=dropout_p, dropout_rng=dropout_rng, kv_grad=kv_grad)
     return out, probs
 
 
@@ -222,6 +224,36 @@ def share_scorer_logits(scorer_logits, n_layers: int, n_heads: int, attention_ma
             s = torch.nn.functional.pad(s, (0, K - s.shape[1]))
         s = attention_mask.reshape(B, K).to(torch.float32) + s
     return ops.share_bias(s, n_layers, n_heads)
+
+
+class EncoderKV:
+    """One decoder layer's share of share_encoder_kv(): key / value [B,h,K,hd] and the slot its dK / dV go to."""
+    __slots__ = ("key", "value", "grad_slot")
+
+    def __init__(self, key, value, grad_slot):
+        self.key, self.value, self.grad_slot = key, value, grad_slot
+
+
+def share_encoder_kv(attn_modules, encoder_hidden_states):
+    """K / V of every decoder layer's cross-attention in one projection.
+
+    The reference runs `c_attn(encoder_hidden_states)` inside every block (my_transformer.py:500-501) on the SAME
+    encoder memory (my_transformer.py:917-928) -- nl GEMMs with N = 2d each, and again for every generated token
+    (my_transformer.py:724-733, 1079-1099).  Call this once per forward, before the block loop, with the blocks'
+    cross-attention modules (anything with a Conv1D-layout `c_attn`), and pass element i as `encoder_kv=` of block i's
+    NuggetCrossAttention: one [B*K, d] x [d, nl*2d] GEMM forward, two GEMMs backward over all layers, and the
+    attention backwards write dK / dV straight into the shared gradient buffer.  Under no_grad the result is the
+    K/V cache of all layers: keep it for the whole generation."""
+    mods = list(attn_modules)
+    if not mods:
+        raise ValueError("share_encoder_kv: no attention modules")
+    dt = encoder_hidden_states.dtype
+    w_all = torch.cat([m.c_attn.weight for m in mods], dim=1).to(dt)
+    b_all = torch.cat([m.c_attn.bias for m in mods], dim=0).to(dt)
+    heads = {m.num_heads for m in mods}
+    if len(heads) != 1:
+        raise ValueError("share_encoder_kv: the layers must have the same number of heads")
+    return [EncoderKV(k, v, slot) for k, v, slot in ops.share_kv(encoder_hidden_states, w_all, b_all, len(mods), heads.pop())]
 
 
 class Conv1D(nn.Module):
@@ -291,19 +323,26 @@ class NuggetCrossAttention(nn.Module):
         return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).permute(0, 2, 1, 3)
 
     def _attn(self, query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
-              limit_cross_attn=False, output_attentions=False):
+              limit_cross_attn=False, output_attentions=False, kv_grad=None):
         return score_biased_attn(query, key, value, attention_mask, head_mask, scorer_logits, limit_cross_attn,
                                  self.scale_attn_weights, self.scale_attn_by_inverse_layer_idx, self.layer_idx,
                                  output_attentions=output_attentions,
-                                 dropout_p=self.attn_pdrop if self.training else 0.0)
+                                 dropout_p=self.attn_pdrop if self.training else 0.0, kv_grad=kv_grad)
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, use_cache=False, output_attentions=False,
-                scorer_logits=None, limit_cross_attn=False):
-        if encoder_hidden_states is None:
+                scorer_logits=None, limit_cross_attn=False, encoder_kv=None):
+        """encoder_kv (not in the reference): this layer's element of share_encoder_kv(); encoder_hidden_states is
+        then not projected again."""
+        if encoder_hidden_states is None and encoder_kv is None:
             raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
         query = self._split_heads(self.q_attn(hidden_states))
-        key, value = self._encoder_kv(encoder_hidden_states)
+        kv_grad = None
+        if encoder_kv is not None:
+            key, value = encoder_kv.key, encoder_kv.value
+            kv_grad = encoder_kv.grad_slot if layer_past is None else None
+        else:
+            key, value = self._encoder_kv(encoder_hidden_states)
         if layer_past is not None:
             past_key, past_value = layer_past
             key = torch.cat((past_key, key), dim=-2)
@@ -311,7 +350,7 @@ class NuggetCrossAttention(nn.Module):
         present = (key, value) if use_cache else None
         attn_output, attn_weights = self._attn(query, key, value, encoder_attention_mask, head_mask, scorer_logits,
                                                limit_cross_attn=bool(limit_cross_attn),
-                                               output_attentions=output_attentions)
+                                               output_attentions=output_attentions, kv_grad=kv_grad)
         # merge heads: the kernel already wrote [B, L, h, hd] memory order
         b, h, l, hd = attn_output.shape
         attn_output = attn_output.permute(0, 2, 1, 3).reshape(b, l, h * hd)

@@ -783,9 +783,11 @@ class _XAttn(torch.autograd.Function):
     """softmax(QK^T*scale + ILK + bias) V with d(bias) = sum_{h,i} dS (my_transformer.py:535-603)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs, dropout_p, dropout_rng):
+    def forward(ctx, q, k, v, bias, key_len, ilk_diag, scale, need_probs, dropout_p, dropout_rng, kv_grad=None):
         ctx.set_materialize_grads(False)
         in_dtype = q.dtype
+        # a slot of share_kv()'s gradient buffer: usable only when the kernels see k / v themselves (no dtype copy)
+        ctx.kv_grad = kv_grad if (k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16) else None
         qb, kb, vb = (t.detach() if t.dtype == torch.bfloat16 else t.detach().to(torch.bfloat16) for t in (q, k, v))
         B, h, L, hd = qb.shape
         dev = qb.device
@@ -826,7 +828,7 @@ class _XAttn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g_probs):
         if g is None:
-            return (None,) * 10
+            return (None,) * 11
         qb, kb, vb, o, lse, bias_f, kl = ctx.saved_tensors
         ilk_diag, scale, bias_len = ctx.cfg
         B, h, L, hd = qb.shape
@@ -840,7 +842,14 @@ class _XAttn(torch.autograd.Function):
             go.copy_(g)
         # the kernels write dQ / dK / dV with the strides of Q / K / V.  Views with gaps (K and V are the two halves of
         # one c_attn output in MyGPT2Attention.forward, my_transformer.py:500-508) are not reproduced by empty_like.
-        dq, dk, dv = _empty_same_strides(qb), _empty_same_strides(kb), _empty_same_strides(vb)
+        dq = _empty_same_strides(qb)
+        dk = dv = None
+        if ctx.kv_grad is not None:
+            # K / V are views of one projection output shared by all decoder layers: dK / dV go straight into the
+            # matching views of the shared gradient buffer (no per-layer allocation of the whole span, no copies)
+            dk, dv = ctx.kv_grad.claim(kb, vb)
+        if dk is None:
+            dk, dv = _empty_same_strides(kb), _empty_same_strides(vb)
         delta = torch.empty((B, h, L), dtype=torch.float32, device=dev)
         dbias = part = None
         if bias_f is not None:
@@ -858,7 +867,7 @@ class _XAttn(torch.autograd.Function):
             dbias = part if bias_len == Kn else part[:, :, :bias_len]
         if dbias is not None and ctx.bias_dtype != torch.float32:
             dbias = dbias.to(ctx.bias_dtype)
-        return dq, dk, dv, dbias, None, None, None, None, None, None
+        return dq, dk, dv, dbias, None, None, None, None, None, None, None
 
 
 class _TypeEmbedAdd(torch.autograd.Function):
@@ -957,14 +966,136 @@ def share_bias(bias, n_layers: int, n_heads: int):
     return _ShareBias.apply(bias, int(n_layers), int(n_heads))
 
 
+class _KVGradBuffer:
+    """dK / dV of nl attention layers in ONE [B, Kn, nl*2*d] buffer laid out like the shared projection output, so
+    that the projection's backward is two GEMMs over all layers.  Allocated when the first gradient arrives, released
+    by the projection's backward."""
+
+    def __init__(self, shape, dtype, device, nl, h):
+        self.shape, self.dtype, self.device, self.nl, self.h = tuple(shape), dtype, device, nl, h
+        self.buf = None
+        self.claimed = set()
+        self.stats = {"in_place": 0, "copied": 0, "zeroed": 0}      # how the last backward's gradients arrived (tests)
+
+    def flat(self):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        return self.buf
+
+    def view(self, i):
+        """view i = 2 * layer + (0 key | 1 value) as [B, h, Kn, hd]"""
+        return _kv_views(self.flat(), self.nl, self.h)[i]
+
+    def release(self):
+        self.buf = None
+        self.claimed.clear()
+
+
+class KVGradSlot:
+    """Where one layer's dK / dV belong in the shared gradient buffer (handed to xattn(kv_grad=...))."""
+
+    def __init__(self, buffer: _KVGradBuffer, layer: int):
+        self.buffer, self.layer = buffer, layer
+
+    def claim(self, kb, vb):
+        """-> (dk, dv) views of the shared buffer with the strides of kb / vb, or (None, None) when the slot was
+        already handed out in this backward (the same K / V used by two attention calls: autograd has to add the
+        two gradients, so the second one needs memory of its own) or does not match."""
+        b = self.buffer
+        i = 2 * self.layer
+        if i in b.claimed or kb.dtype != b.dtype:
+            return None, None
+        dk, dv = b.view(i), b.view(i + 1)
+        if dk.shape != kb.shape or dk.stride() != kb.stride() or dv.shape != vb.shape or dv.stride() != vb.stride():
+            return None, None
+        b.claimed.add(i)
+        return dk, dv
+
+
+def _kv_views(kv, nl, h):
+    """kv [B, Kn, nl*2*d] -> [k_0, v_0, k_1, v_1, ...] as [B, h, Kn, hd] views (split_heads of the two halves of
+    every layer's c_attn output, my_transformer.py:500-508)."""
+    B, Kn, n = kv.shape
+    hd = n // (2 * nl * h)
+    t = kv.view(B, Kn, nl, 2, h, hd)
+    return [t[:, :, l, i].permute(0, 2, 1, 3) for l in range(nl) for i in range(2)]
+
+
+class _ShareKV(torch.autograd.Function):
+    """c_attn of nl decoder layers on the same encoder memory (my_transformer.py:500-501, 917-928) as ONE GEMM
+    [B*Kn, d] x [d, nl*2d]; backward: dmem = dKV W^T and dW = mem^T dKV over all layers at once, with dKV assembled in
+    place by the attention backwards (KVGradSlot)."""
+
+    @staticmethod
+    def forward(ctx, mem, w_all, b_all, nl, h, gbuf):
+        ctx.set_materialize_grads(False)
+        B, Kn, d = mem.shape
+        m2 = mem.detach().reshape(B * Kn, d)
+        wd = w_all.detach()
+        kv = torch.addmm(b_all.detach(), m2, wd).view(B, Kn, -1)
+        ctx.save_for_backward(m2, wd)
+        ctx.gbuf = gbuf
+        ctx.mem_shape = (B, Kn, d)
+        return tuple(_kv_views(kv, nl, h))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            ctx.gbuf.release()
+            return (None,) * 6
+        m2, wd = ctx.saved_tensors
+        gbuf = ctx.gbuf
+        gbuf.stats = {"in_place": 0, "copied": 0, "zeroed": 0}
+        for i, g in enumerate(grads):
+            slot = gbuf.view(i)
+            if g is None:
+                slot.zero_()
+                gbuf.stats["zeroed"] += 1
+            elif g.data_ptr() == slot.data_ptr() and g.stride() == slot.stride() and g.dtype == slot.dtype:
+                gbuf.stats["in_place"] += 1
+            else:
+                slot.copy_(g)                           # a gradient that was not written in place (fallback)
+                gbuf.stats["copied"] += 1
+        dkv = gbuf.flat().view(m2.shape[0], -1)
+        dmem = (dkv @ wd.t()).view(ctx.mem_shape) if ctx.needs_input_grad[0] else None
+        dw = (m2.t() @ dkv) if ctx.needs_input_grad[1] else None
+        db = dkv.sum(0) if ctx.needs_input_grad[2] else None
+        gbuf.release()
+        return dmem, dw, db, None, None, None
+
+
+def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int):
+    """K / V of n_layers cross-attention layers from ONE projection of the encoder memory.
+
+    mem [B, Kn, d]; w_all [d, n_layers*2*d] = the layers' c_attn weights (HF Conv1D layout [in, out]) side by side,
+    b_all [n_layers*2*d].  Returns a list of (key, value, slot) per layer: key / value are [B, h, Kn, hd] views of the
+    projection output, slot is the KVGradSlot to pass as xattn(kv_grad=slot) so that the layer's dK / dV are written
+    straight into the shared gradient buffer.  Pure torch apart from that hand-over: runs on any device."""
+    if mem.dim() != 3 or w_all.dim() != 2 or w_all.shape[0] != mem.shape[2]:
+        raise ValueError(f"share_kv: mem {tuple(mem.shape)} / w_all {tuple(w_all.shape)}: want [B,Kn,d] and [d, nl*2*d]")
+    d = mem.shape[2]
+    if w_all.shape[1] != n_layers * 2 * d or b_all.shape != (n_layers * 2 * d,):
+        raise ValueError(f"share_kv: w_all / b_all must have {n_layers}*2*{d} columns, got {tuple(w_all.shape)} / "
+                         f"{tuple(b_all.shape)}")
+    if d % n_heads:
+        raise ValueError("share_kv: d must be divisible by n_heads")
+    if not (mem.dtype == w_all.dtype == b_all.dtype):
+        raise TypeError("share_kv: mem, w_all and b_all must share one dtype")
+    B, Kn, _ = mem.shape
+    gbuf = _KVGradBuffer((B, Kn, n_layers * 2 * d), mem.dtype, mem.device, int(n_layers), int(n_heads))
+    outs = _ShareKV.apply(mem, w_all, b_all, int(n_layers), int(n_heads), gbuf)
+    return [(outs[2 * l], outs[2 * l + 1], KVGradSlot(gbuf, l)) for l in range(n_layers)]
+
+
 def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[float] = None,
-          need_probs: bool = False, dropout_p: float = 0.0, dropout_rng=None):
+          need_probs: bool = False, dropout_p: float = 0.0, dropout_rng=None, kv_grad=None):
     """q [B,h,L,hd]; k, v [B,h,Kn,hd]; bias [B,bias_len<=Kn] fp32 added to every query's logits (keys past
     bias_len get 0: the prefix-bias variant, my_transformer.py:114-125); key_len [B] masks keys >= key_len[b];
     ilk_diag >= 0 enables the infinite-lookback mask (key j visible iff j <= i+diag).
     dropout_p > 0: attention-probability dropout (my_transformer.py:595) with the counter-based mask specified in
     star_nugget.h; dropout_rng = (seed, offset) host integers for a reproducible mask, a device int64[2] tensor, or
     None to draw from the per-device state seeded by torch's generator.
+    kv_grad: the KVGradSlot that share_kv() returned with this layer's k and v (optional; see there).
     Returns (O [B,h,L,hd] (memory order [B,L,h,hd]), P or None); P holds the dropped, rescaled weights."""
     _need_cuda(q, k, v, bias, key_len)
     if scale is None:
@@ -972,7 +1103,7 @@ def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[
     if not 0.0 <= dropout_p < 1.0:
         raise ValueError(f"xattn: dropout_p = {dropout_p} not in [0, 1)")
     return _XAttn.apply(q, k, v, bias, key_len, int(ilk_diag), float(scale), bool(need_probs), float(dropout_p),
-                        dropout_rng)
+                        dropout_rng, kv_grad)
 
 
 def test_override(which: int, value: int) -> int:

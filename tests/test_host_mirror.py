@@ -88,3 +88,68 @@ def test_error_behaviour_without_a_gpu():
         star_amd.share_scorer_logits(torch.zeros(2, 5), 3, 4)
     with pytest.raises(star_amd.ops.StarDeviceError):
         star_amd.ops.type_embed_add(torch.zeros(2, 3, 8), torch.zeros(2, 3, dtype=torch.long), torch.zeros(2, 8))
+
+
+def _torch_attn(q, k, v):
+    p = torch.softmax(q @ k.transpose(-1, -2) / q.shape[-1] ** 0.5, dim=-1)
+    return p @ v
+
+
+def test_share_encoder_kv_equals_per_layer_c_attn_cpu():
+    """one projection for all layers == c_attn + split_heads of every layer
+    (my_transformer.py:500-508), values and gradients (CPU: the gradients arrive through the copy fallback)."""
+    torch.manual_seed(3)
+    B, K, L, d, h, nl = 2, 7, 5, 32, 4, 3
+    mods = [NuggetCrossAttention(d, h, layer_idx=i) for i in range(nl)]
+    for m in mods:
+        torch.nn.init.normal_(m.c_attn.bias, std=0.1)
+    mem = torch.randn(B, K, d, requires_grad=True)
+    qs = [torch.randn(B, h, L, d // h) for _ in range(nl)]
+    gs = [torch.randn(B, h, L, d // h) for _ in range(nl)]
+
+    def run(shared):
+        for m in mods:
+            m.zero_grad()
+        mem.grad = None
+        if shared:
+            kvs = star_amd.share_encoder_kv(mods, mem)
+            pairs = [(e.key, e.value) for e in kvs]
+            assert all(e.grad_slot.layer == i for i, e in enumerate(kvs))
+        else:
+            pairs = []
+            for m in mods:
+                k, v = m.c_attn(mem).split(d, dim=2)
+                pairs.append((m._split_heads(k), m._split_heads(v)))
+        loss = sum((_torch_attn(q, k, v) * g).sum() for q, (k, v), g in zip(qs, pairs, gs))
+        loss.backward()
+        return ([t.detach().clone() for kv in pairs for t in kv], mem.grad.clone(),
+                [m.c_attn.weight.grad.clone() for m in mods], [m.c_attn.bias.grad.clone() for m in mods])
+
+    ref, got = run(False), run(True)
+    for a, b in zip(ref[0], got[0]):
+        assert a.shape == b.shape == (B, h, K, d // h)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-5)
+    for a, b in zip(ref[2] + ref[3], got[2] + got[3]):
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-5)
+
+
+def test_share_encoder_kv_unused_layer_and_errors():
+    torch.manual_seed(4)
+    B, K, d, h = 2, 5, 16, 2
+    mods = [NuggetCrossAttention(d, h) for _ in range(2)]
+    mem = torch.randn(B, K, d, requires_grad=True)
+    kvs = star_amd.share_encoder_kv(mods, mem)
+    (kvs[1].key.sum() * 2.0).backward()                    # layer 0 and V of layer 1 get no gradient: zeros, not garbage
+    assert torch.count_nonzero(mods[0].c_attn.weight.grad) == 0
+    assert torch.count_nonzero(mods[1].c_attn.weight.grad[:, d:]) == 0
+    torch.testing.assert_close(mods[1].c_attn.bias.grad[:d], torch.full((d,), 2.0 * B * K))
+    assert mem.grad is not None and torch.isfinite(mem.grad).all()
+    with pytest.raises(ValueError):
+        star_amd.share_encoder_kv([], mem)
+    with pytest.raises(ValueError):
+        star_amd.share_encoder_kv([NuggetCrossAttention(d, 2), NuggetCrossAttention(d, 4)], mem)
+    with pytest.raises(ValueError):
+        star_amd.ops.share_kv(mem, torch.zeros(d, 3 * d), torch.zeros(3 * d), 2, h)
+    with pytest.raises(TypeError):
+        star_amd.ops.share_kv(mem, torch.zeros(d, 4 * d, dtype=torch.bfloat16), torch.zeros(4 * d), 2, h)

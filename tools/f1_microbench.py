@@ -52,3 +52,27 @@ with torch.no_grad():
 print(f"forward today: c_attn {t_c:.1f} + q_attn {t_q:.1f} + core {t_f:.1f} + c_proj {t_p:.1f} = {t_c + t_q + t_f + t_p:.1f} us per layer")
 print(f"K/V round trip through HBM: {2 * 2.0 * B * K * d * 2 / 1e6:.1f} MB written by c_attn and read by the core; "
       f"the memory itself is {2.0 * B * K * d / 1e6:.1f} MB")
+
+# ---- step (1) of the design note: ONE c_attn GEMM for all decoder layers (the memory is the same for every layer)
+nl = 4
+with torch.no_grad():
+    w_all = torch.randn(d, nl * 2 * d, device=dev).bfloat16() * 0.02
+    b_all = torch.zeros(nl * 2 * d, device=dev).bfloat16()
+    ws = [w_all[:, i * 2 * d:(i + 1) * 2 * d].contiguous() for i in range(nl)]
+    bs = [b_all[i * 2 * d:(i + 1) * 2 * d].contiguous() for i in range(nl)]
+    M = B * K
+    fl = 2.0 * M * d * nl * 2 * d
+    by = 2.0 * (M * d + nl * 2 * d * d + M * nl * 2 * d)
+    t4 = timeit("c_attn x 4 layers, one launch each", lambda: [torch.addmm(bs[i], mem.view(-1, d), ws[i]) for i in range(nl)],
+                flops=fl, bytes_=by + 3 * 2.0 * M * d)
+    t1 = timeit("c_attn, all layers in one GEMM (N = 8192)", lambda: torch.addmm(b_all, mem.view(-1, d), w_all),
+                flops=fl, bytes_=by)
+    tcat = timeit("torch.cat of the 4 weights + biases", lambda: (torch.cat(ws, 1), torch.cat(bs, 0)))
+    dkv = torch.randn(M, nl * 2 * d, device=dev).bfloat16()
+    dkvs = [dkv[:, i * 2 * d:(i + 1) * 2 * d].contiguous() for i in range(nl)]
+    m2 = mem.view(-1, d)
+    tb4 = timeit("backward x 4: dmem += dKV W^T, dW = mem^T dKV",
+                 lambda: [(dkvs[i] @ ws[i].t(), m2.t() @ dkvs[i]) for i in range(nl)], flops=2 * fl)
+    tb1 = timeit("backward, all layers: dmem = dKV W^T, dW = mem^T dKV", lambda: (dkv @ w_all.t(), m2.t() @ dkv),
+                 flops=2 * fl)
+print(f"all-layer c_attn: forward {t4:.1f} -> {t1:.1f} (+ cat {tcat:.1f}) us, backward {tb4:.1f} -> {tb1:.1f} us per step")
