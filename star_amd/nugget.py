@@ -319,6 +319,13 @@ class NuggetCrossAttention(nn.Module):
         self._kv_cache = (tag, key, value, encoder_hidden_states) if cacheable else None
         return key, value
 
+    def _encoder_kv_train(self, encoder_hidden_states):
+        """Grad-enabled form of the same projection: split + split_heads through ops.split_kv, so that the attention
+        backward writes dK / dV into the two halves of ONE [B,K,2d] gradient (what c_attn's backward consumes)
+        instead of two gapped tensors that autograd then concatenates."""
+        self._kv_cache = None                           # grad-enabled calls never cache
+        return ops.split_kv(self.c_attn(encoder_hidden_states), 1, self.num_heads)[0]
+
     def _split_heads(self, t):
         return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).permute(0, 2, 1, 3)
 
@@ -341,6 +348,8 @@ class NuggetCrossAttention(nn.Module):
         if encoder_kv is not None:
             key, value = encoder_kv.key, encoder_kv.value
             kv_grad = encoder_kv.grad_slot if layer_past is None else None
+        elif torch.is_grad_enabled() and encoder_hidden_states.dim() == 3 and layer_past is None:
+            key, value, kv_grad = self._encoder_kv_train(encoder_hidden_states)
         else:
             key, value = self._encoder_kv(encoder_hidden_states)
         if layer_past is not None:

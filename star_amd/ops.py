@@ -1021,30 +1021,24 @@ def _kv_views(kv, nl, h):
     return [t[:, :, l, i].permute(0, 2, 1, 3) for l in range(nl) for i in range(2)]
 
 
-class _ShareKV(torch.autograd.Function):
-    """c_attn of nl decoder layers on the same encoder memory (my_transformer.py:500-501, 917-928) as ONE GEMM
-    [B*Kn, d] x [d, nl*2d]; backward: dmem = dKV W^T and dW = mem^T dKV over all layers at once, with dKV assembled in
-    place by the attention backwards (KVGradSlot)."""
+class _SplitKV(torch.autograd.Function):
+    """split + split_heads of a c_attn output that holds the K | V columns of nl layers side by side
+    (my_transformer.py:500-508): forward hands out 2*nl [B,h,Kn,hd] views; backward returns ONE [B,Kn,nl*2*d]
+    gradient that the attention backwards assembled in place (KVGradSlot), so the projection's backward is two GEMMs
+    over all layers and nothing is concatenated."""
 
     @staticmethod
-    def forward(ctx, mem, w_all, b_all, nl, h, gbuf):
+    def forward(ctx, kv, nl, h, gbuf):
         ctx.set_materialize_grads(False)
-        B, Kn, d = mem.shape
-        m2 = mem.detach().reshape(B * Kn, d)
-        wd = w_all.detach()
-        kv = torch.addmm(b_all.detach(), m2, wd).view(B, Kn, -1)
-        ctx.save_for_backward(m2, wd)
         ctx.gbuf = gbuf
-        ctx.mem_shape = (B, Kn, d)
-        return tuple(_kv_views(kv, nl, h))
+        return tuple(_kv_views(kv.detach(), nl, h))
 
     @staticmethod
     def backward(ctx, *grads):
-        if all(g is None for g in grads):
-            ctx.gbuf.release()
-            return (None,) * 6
-        m2, wd = ctx.saved_tensors
         gbuf = ctx.gbuf
+        if all(g is None for g in grads):
+            gbuf.release()
+            return None, None, None, None
         gbuf.stats = {"in_place": 0, "copied": 0, "zeroed": 0}
         for i, g in enumerate(grads):
             slot = gbuf.view(i)
@@ -1056,21 +1050,31 @@ class _ShareKV(torch.autograd.Function):
             else:
                 slot.copy_(g)                           # a gradient that was not written in place (fallback)
                 gbuf.stats["copied"] += 1
-        dkv = gbuf.flat().view(m2.shape[0], -1)
-        dmem = (dkv @ wd.t()).view(ctx.mem_shape) if ctx.needs_input_grad[0] else None
-        dw = (m2.t() @ dkv) if ctx.needs_input_grad[1] else None
-        db = dkv.sum(0) if ctx.needs_input_grad[2] else None
+        dkv = gbuf.flat()
         gbuf.release()
-        return dmem, dw, db, None, None, None
+        return dkv, None, None, None
+
+
+def split_kv(kv, n_layers: int, n_heads: int):
+    """kv [B, Kn, n_layers*2*d] (the c_attn outputs of n_layers layers side by side; n_layers = 1: one layer's
+    c_attn output) -> list of (key, value, slot) per layer: key / value are [B, h, Kn, hd] views, slot is the
+    KVGradSlot to pass as xattn(kv_grad=slot) so that the layer's dK / dV are written straight into the one gradient
+    tensor that flows back into the projection.  Pure torch apart from that hand-over: runs on any device."""
+    if kv.dim() != 3 or kv.shape[2] % (2 * n_layers * n_heads):
+        raise ValueError(f"split_kv: kv {tuple(kv.shape)}: want [B, Kn, {n_layers}*2*d] with d divisible by {n_heads}")
+    if not kv.is_contiguous():
+        kv = kv.contiguous()
+    gbuf = _KVGradBuffer(kv.shape, kv.dtype, kv.device, int(n_layers), int(n_heads))
+    outs = _SplitKV.apply(kv, int(n_layers), int(n_heads), gbuf)
+    return [(outs[2 * l], outs[2 * l + 1], KVGradSlot(gbuf, l)) for l in range(n_layers)]
 
 
 def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int):
     """K / V of n_layers cross-attention layers from ONE projection of the encoder memory.
 
     mem [B, Kn, d]; w_all [d, n_layers*2*d] = the layers' c_attn weights (HF Conv1D layout [in, out]) side by side,
-    b_all [n_layers*2*d].  Returns a list of (key, value, slot) per layer: key / value are [B, h, Kn, hd] views of the
-    projection output, slot is the KVGradSlot to pass as xattn(kv_grad=slot) so that the layer's dK / dV are written
-    straight into the shared gradient buffer.  Pure torch apart from that hand-over: runs on any device."""
+    b_all [n_layers*2*d].  One GEMM forward; backward dmem = dKV W^T and dW = mem^T dKV over all layers at once.
+    Returns split_kv() of the projection output."""
     if mem.dim() != 3 or w_all.dim() != 2 or w_all.shape[0] != mem.shape[2]:
         raise ValueError(f"share_kv: mem {tuple(mem.shape)} / w_all {tuple(w_all.shape)}: want [B,Kn,d] and [d, nl*2*d]")
     d = mem.shape[2]
@@ -1082,9 +1086,8 @@ def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int):
     if not (mem.dtype == w_all.dtype == b_all.dtype):
         raise TypeError("share_kv: mem, w_all and b_all must share one dtype")
     B, Kn, _ = mem.shape
-    gbuf = _KVGradBuffer((B, Kn, n_layers * 2 * d), mem.dtype, mem.device, int(n_layers), int(n_heads))
-    outs = _ShareKV.apply(mem, w_all, b_all, int(n_layers), int(n_heads), gbuf)
-    return [(outs[2 * l], outs[2 * l + 1], KVGradSlot(gbuf, l)) for l in range(n_layers)]
+    kv = torch.addmm(b_all, mem.reshape(B * Kn, d), w_all).view(B, Kn, -1)
+    return split_kv(kv, n_layers, n_heads)
 
 
 def xattn(q, k, v, bias=None, key_len=None, ilk_diag: int = -1, scale: Optional[float] = None,
