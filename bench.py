@@ -321,13 +321,20 @@ def main():
         # the training forward: it also emits the ReLU sign bits the backward consumes
         bits = torch.empty(_lib.lib().star_scorer_relu_bits_bytes(N, d), dtype=torch.uint8, device=dev)
 
-        valid = inp.valid                          # ragged batch: the launch the step makes skips all-padding row tiles
+        valid = inp.valid                          # ragged batch: the launch the step makes computes the valid frames only
 
         def launch():
             if valid is None:
                 _lib.check(_lib.lib().star_scorer_fwd(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
                                                       b2f.data_ptr(), N, d, sc.data_ptr(), bits.data_ptr(), ws.data_ptr(),
                                                       wsb, _lib.stream_ptr()), "star_scorer_fwd")
+            elif valid.compact:
+                _lib.check(_lib.lib().star_scorer_fwd_compact(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
+                                                              b2f.data_ptr(), valid.lengths.data_ptr(),
+                                                              valid.offsets.data_ptr(), valid._rows_ptr.data_ptr(),
+                                                              valid.n_valid, B, T, d, sc.data_ptr(), bits.data_ptr(),
+                                                              ws.data_ptr(), wsb, _lib.stream_ptr()),
+                           "star_scorer_fwd_compact")
             else:
                 _lib.check(_lib.lib().star_scorer_fwd_ragged(xb.data_ptr(), w1b.data_ptr(), b1f.data_ptr(), w2f.data_ptr(),
                                                              b2f.data_ptr(), valid.lengths.data_ptr(), B, T, d,
@@ -338,7 +345,7 @@ def main():
         legs_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(legs_stream)
         avg_us = event_time_us(launch, iters=max(args.steps, 10), graph=False)
-        # algorithmic work: the valid frames only (a ragged launch also computes the pad frames of its partly filled tiles)
+        # algorithmic work: the valid frames only
         flops = float(N if valid is None else valid.n_valid) * (2.0 * d * d + 2.0 * d)
         ach = flops / (avg_us * 1e-6) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_SCORE> (+ scorer_finish_kernel)", "achieved": round(ach, 2),
@@ -346,8 +353,9 @@ def main():
                     "traffic": pmc_traffic(N, d) if valid is None else None, "avg_us": round(avg_us, 2),
                     "flop_per_launch": flops,
                     "launch": "star_scorer_fwd" if valid is None else
-                    "star_scorer_fwd_ragged: %d of %d row tiles computed, %d valid frames" % (valid.n_live, (N + 255) // 256,
-                                                                                          valid.n_valid)}
+                    ("star_scorer_fwd_compact: the %d valid of %d frames, gathered" % (valid.n_valid, N) if valid.compact else
+                     "star_scorer_fwd_ragged: %d of %d row tiles computed, %d valid frames" % (valid.n_live, (N + 255) // 256,
+                                                                                           valid.n_valid))}
         if not args.no_roofline_all:
             roofline_all = roofline_legs(ops, scorer, inp, wl, rate, dev, roofline)
         torch.cuda.synchronize()

@@ -46,7 +46,9 @@ const char* star_last_error(void);
 #define STAR_OVR_XA_DKV 2  /* 1 = the general dK/dV kernel */
 #define STAR_OVR_XA_NG 3   /* key groups of the register-staged attention forward / general dQ: 1 or 2 */
 #define STAR_OVR_XA_FWD 4  /* attention forward: 1 = the register-staged kernel instead of the LDS-DMA ring */
-#define STAR_OVR_COUNT 5
+#define STAR_OVR_SCORER_NT 5 /* scorer backward dW1 GEMM: 1 = NT on transposed copies, 2 = TN on the row-major operands
+                              (0: TN from 16384 rows up) */
+#define STAR_OVR_COUNT 6
 int star_test_override(int which, int value);
 
 /* ---------------------------------------------------------------- a2 + a3: top-k anchor select
@@ -265,6 +267,20 @@ int star_scorer_fwd_ragged(const void* x, const void* w1, const float* b1, const
                            const int32_t* lengths, int B, int T, int d, const int32_t* live_tiles, int n_live,
                            float* scores, void* relu_bits, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* Compact ragged form: the GEMM runs on the valid frames only (gathered through `rows`), so no row of a computed tile
+ * is padding: at MuST-C-shaped lengths (median 300 of T = 1500 frames) the 256-row live tiles of the form above are
+ * 60 % full.  Same observable results (pad frames score 0; valid frames as star_scorer_fwd up to the summation order
+ * inside the MFMA tiles, which does not depend on the row).  No counterpart in the reference (it scores every padded
+ * frame, w2v_asr.py:553, w2v_simul.py:411).
+ *   lengths [B] int32, offsets [B] int32 = exclusive prefix sum of lengths, rows [n_valid] int32 = the frame ids
+ *   b*T + t of the valid frames in ascending order (so frame (b,t) is row offsets[b] + t) -- all on the device;
+ *   star_amd.ops.ValidFrames builds the three from the lengths.
+ *   relu_bits: as star_scorer_fwd, but indexed by ROW of the compacted list: hand star_scorer_bwd_mapped the row of
+ *   every listed frame (bit_rows).  workspace: star_scorer_fwd_workspace(n_valid, d) bytes. */
+int star_scorer_fwd_compact(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                            const int32_t* lengths, const int32_t* offsets, const int32_t* rows, int64_t n_valid,
+                            int B, int T, int d, float* scores, void* relu_bits, void* workspace,
+                            size_t workspace_bytes, void* stream);
 /* star_scorer_fwd without a workspace argument and without any allocation.  NO counterpart in the reference: it is
  * for callers that cannot allocate device memory around the call (code under HIP-graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  The partial scores go to a file-scope __device__ array of
@@ -300,6 +316,13 @@ int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, const float
                     int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
                     int dx_zeroed, void* workspace, size_t workspace_bytes, void* stream,
                     void* aux_stream, void* const* aux_events_host);
+/* star_scorer_bwd for relu_bits written by star_scorer_fwd_compact: bit_rows [R] int32 (device) = the forward's row
+ * (offsets[b] + t) of every frame listed in rows[]; NULL = the frame ids themselves (star_scorer_bwd). */
+int star_scorer_bwd_mapped(const void* x, const void* w1, const void* w1ts, const float* b1, const float* w2,
+                           const void* relu_bits, const float* dscores, const int32_t* rows, const int32_t* bit_rows,
+                           int64_t R, int64_t N, int d, float* dw1, float* db1, float* dw2, float* db2, void* dx,
+                           int dx_zeroed, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
+                           void* const* aux_events_host);
 /* fp32 [rows,cols] -> bf16 copy (dst, may be NULL) and bf16 transpose (dst_t, may be NULL): the per-step weight cast
  * of W1.  t_scale [rows] fp32 or NULL: dst_t[c][r] = bf16(src[r][c] * t_scale[r]) (dst is never scaled). */
 int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, const float* t_scale,

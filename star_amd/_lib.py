@@ -67,10 +67,13 @@ SIGNATURES = {
     "star_scorer_relu_bits_bytes": (_SZ, [_I64, _I]),
     "star_scorer_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P, _SZ, _P]),
     "star_scorer_fwd_ragged": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _SZ, _P]),
+    "star_scorer_fwd_compact": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P, _SZ, _P]),
     "star_scorer_fwd_static": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P, _P, _P]),
     "star_scorer_bwd_workspace": (_SZ, [_I64, _I]),
     "star_scorer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ, _P, _P,
                              C.POINTER(C.c_void_p)]),
+    "star_scorer_bwd_mapped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ,
+                                    _P, _P, C.POINTER(C.c_void_p)]),
     "star_cast_transpose_bf16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "star_xattn_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P]),
     "star_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -503,20 +503,228 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
   }
 }
 
-// scores[m] = b2 + sum over column tiles of partial[t][m]   (fixed order -> reproducible)
-// lengths (ragged form): frame m = b*T + t is valid iff t < lengths[b]; the other frames get score 0 (their row tile
-// may not have been computed at all)
+// ---------------------------------------------------------------------------------------------------------------
+// "TN" GEMM for the scorer backward: U[n][k] = sum_r G'[r][n] * X[rows[r]][k] with BOTH operands stored row-major by
+// the reduction index r (G' [Rpad][d] as the G' pass writes it, X gathered through rows[]): no G'^T, no X_sel^T pass.
+// Same 256 x 256 x 64 tile, 8 waves, phases, barriers and LDS-DMA ring as gemm_nt_kernel; what differs:
+//   * a half-tile is [64 r][128 columns] (256-byte rows); A-half h = columns m0 + 128 h .. + 127 of G', B-half h =
+//     columns n0 + 128 h .. + 127 of X, so every staged row piece is 256 contiguous bytes.  Wave (wr, wc) owns output
+//     rows {128 h + 64 wr + 0..63} and columns {128 h + 32 wc + 0..31}, h = 0, 1 (the four accumulator quadrants);
+//   * MFMA fragments (8 consecutive r of one column per lane) come from ds_read_b64_tr_b16 (4 r x 16 columns per
+//     16-lane group, two reads per fragment).  Conflict-free with the 32-byte windows of a row XOR-ed by
+//     key(r) = (r & 3) | ((r >> 3) & 1) << 2: the 8 rows one half-wave reads fall into 8 different windows.  The DMA
+//     applies the same involution to the source chunk;
+//   * the row ids of the workgroup's r range are parked in LDS behind the ring before the loop (one ds_read per staged
+//     row piece instead of a register-destination global load inside the counted-vmcnt pipeline).
+constexpr int TN_MAX_ROWS = 7168;                                  // r range per workgroup (28 KiB of row ids)
+constexpr int TN_LDS = GEMM_LDS + TN_MAX_ROWS * 4;
+static_assert(TN_LDS <= 160 * 1024, "ring + row ids must fit the CU");
+__device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    // blocks b and b+8 share an XCD: all column tiles of one (row panel, r split) run on one XCD (they share G' rows)
+    const int vb = blockIdx.x;
+    const int xcd = vb & 7, local = vb >> 3;
+    const int panel = (local / nbn) * 8 + xcd;
+    const int n_tile = local % nbn;
+    if (panel >= nbm * p.splits) return;
+    const int m_tile = panel % nbm, split = panel / nbm;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int cps = (p.kchunks + p.splits - 1) / p.splits;
+    const int kc0 = split * cps;
+    const int kc1 = min(p.kchunks, kc0 + cps);
+    const int nk = max(0, kc1 - kc0);
+
+    // row ids of this workgroup's r range (rows past the list repeat entry 0: their G' rows are zero): parked in LDS
+    // behind the ring -- after the prologue's DMA is on its way, see below
+    int* rows_lds = (int*)(lds + GEMM_LDS);
+    auto gathered = [&](int r) { return p.a_rows ? p.a_rows[r < p.a_rows_n ? r : 0] : min(r, p.a_rows_n - 1); };
+
+    // staging geometry: wave w stages pieces 2w, 2w+1 (4 rows x 256 B each) of every half-tile; lane l -> row
+    // piece*4 + (l >> 4), LDS chunk position l & 15, source chunk = the same position with its 32-byte window XOR-ed
+    int srow[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        srow[i] = (wid * 2 + i) * 4 + (lane >> 4);
+        const int cpos = lane & 15;
+        scol[i] = ((((cpos >> 1) ^ tn_key(srow[i])) << 1) | (cpos & 1)) * 8;          // element column 0..127
+    }
+    const __bf16* asrc[2][2];            // [half][piece]: G' + (kc0*64 + row) * lda + column
+    int bcol[2][2];                      // [half][piece]: X column
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ca = m0 + h * 128 + scol[i];
+            if (ca > p.M - 8) ca = p.M - 8;
+            asrc[h][i] = p.A + ((int64_t)kc0 * BK + srow[i]) * p.lda + ca;
+            int cb = n0 + h * 128 + scol[i];
+            if (cb > p.N - 8) cb = p.N - 8;
+            bcol[h][i] = cb;
+        }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define STAR_TN_STAGE_A(H, TT)                                                                               \
+    do {                                                                                                     \
+        if ((TT) < nk) {                                                                                     \
+            uint8_t* dst_ = lds + ((TT) & 1) * BUF_BYTES + ((H) ? H_A1 : H_A0) * HALF_BYTES + wid * 2048;     \
+            glds16(asrc[H][0] + (int64_t)(TT) * BK * p.lda, dst_);                                           \
+            glds16(asrc[H][1] + (int64_t)(TT) * BK * p.lda, dst_ + 1024);                                    \
+        }                                                                                                    \
+    } while (0)
+#define STAR_TN_STAGE_B(H, TT, R0, R1)                                                                       \
+    do {                                                                                                     \
+        if ((TT) < nk) {                                                                                     \
+            uint8_t* dst_ = lds + ((TT) & 1) * BUF_BYTES + ((H) ? H_B1 : H_B0) * HALF_BYTES + wid * 2048;     \
+            glds16(p.B + (int64_t)(R0) * p.ldb + bcol[H][0], dst_);                                          \
+            glds16(p.B + (int64_t)(R1) * p.ldb + bcol[H][1], dst_ + 1024);                                   \
+        }                                                                                                    \
+    } while (0)
+    auto row_id = [&](int tt, int i) { return rows_lds[min(tt, nk - 1) * BK + srow[i]]; };
+
+    // fragment reads (see the header comment): lane (i16, g) reads row 8 g + (i16 >> 2) (+4), 8 bytes at 8 (i16 & 3)
+    // of window (win ^ key); key is the same for both reads and both k steps
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int key = (i16 >> 2) | ((g4 & 1) << 2);
+    const int rbase = (8 * g4 + (i16 >> 2)) * 256 + 8 * (i16 & 3);
+    bf16x8 af[4][2], bfr[2][2][2];
+    auto tr8 = [&](const uint8_t* q) -> bf16x8 {
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * 256));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto read_a = [&](int buf, int mh) {
+        const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + rbase;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = ((wr * 4 + i) ^ key) << 5;
+            af[i][0] = tr8(base + off);
+            af[i][1] = tr8(base + 32 * 256 + off);
+        }
+    };
+    auto read_b = [&](int buf, int nh) {
+        const uint8_t* base = lds + buf * BUF_BYTES + (nh ? H_B1 : H_B0) * HALF_BYTES + rbase;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = ((wc * 2 + j) ^ key) << 5;
+            bfr[nh][j][0] = tr8(base + off);
+            bfr[nh][j][1] = tr8(base + 32 * 256 + off);
+        }
+    };
+#define STAR_TN_MMA(MH, NH)                                                                                  \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                    acc[4 * (MH) + i][2 * (NH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(               \
+                        af[i][ks], bfr[NH][j][ks], acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0);                \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+
+    if (nk > 0) {
+        // prologue: all of K tile 0 and three half-tiles of K tile 1 (seven half-tiles ahead, as in the loop).  The G'
+        // halves of tile 0 go first (they need no row id); the row ids of tiles 0 and 1 are loaded by the staging
+        // lanes themselves, so the first X pieces wait for one global load, not for an LDS round trip and a barrier.
+        const int rr0 = kc0 * BK + srow[0], rr1 = kc0 * BK + srow[1];
+        const int step1 = nk > 1 ? BK : 0;
+        const int r0 = gathered(rr0), r1 = gathered(rr1), q0 = gathered(rr0 + step1), q1 = gathered(rr1 + step1);
+        STAR_TN_STAGE_A(0, 0);
+        STAR_TN_STAGE_A(1, 0);
+        STAR_TN_STAGE_B(0, 0, r0, r1);
+        STAR_TN_STAGE_B(1, 0, r0, r1);
+        if (nk > 1) {
+            STAR_TN_STAGE_B(0, 1, q0, q1);
+            STAR_TN_STAGE_A(0, 1);
+            STAR_TN_STAGE_B(1, 1, q0, q1);
+        }
+        for (int i = tid; i < nk * BK; i += GEMM_THREADS) rows_lds[i] = gathered(kc0 * BK + i);
+        __syncthreads();            // row ids visible, K tile 0 (and the staged part of tile 1) landed
+
+        if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier behind the first
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < nk; ++t) {
+            const int buf = t & 1;
+            const int n0r = row_id(t + 2, 0), n1r = row_id(t + 2, 1);     // rows of K tile t + 2
+            // phase 1: quadrant (0,0).  The B reads go first: lgkmcnt(15) retires at least the first 9 of the 24 reads
+            // in flight (all 8 of B-half 0) before the barrier; that half-tile slot is re-staged in the next phase.
+            read_b(buf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(buf, 0);
+            STAR_TN_STAGE_A(1, t + 1);
+            __builtin_amdgcn_s_waitcnt(0xCF7F);         // lgkmcnt(15)
+            STAR_TN_MMA(0, 0);
+            // phase 2: quadrant (0,1)
+            read_b(buf, 1);
+            STAR_TN_STAGE_B(0, t + 2, n0r, n1r);
+            STAR_TN_MMA(0, 1);
+            // phase 3: quadrant (1,1)
+            read_a(buf, 1);
+            STAR_TN_STAGE_A(0, t + 2);
+            STAR_TN_MMA(1, 1);
+            // phase 4: quadrant (1,0)
+            STAR_TN_STAGE_B(1, t + 2, n0r, n1r);
+            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAR_TN_MMA(1, 0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();      // pairs with the second wave row's last barrier
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef STAR_TN_STAGE_A
+#undef STAR_TN_STAGE_B
+#undef STAR_TN_MMA
+
+    // fp32 split slab: C layout of mfma_f32_16x16x32 is col = lane & 15, row = (lane >> 4) * 4 + j
+    const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
+    float* slab = p.slab + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + (tm >> 2) * 128 + wr * 64 + (tm & 3) * 16 + crow4 + j;
+                const int n = n0 + (tn >> 1) * 128 + wc * 32 + (tn & 1) * 16 + ccol;
+                if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
+            }
+}
+
+// scores[m] = b2 + sum over column tiles of partial[t][row(m)]   (fixed order -> reproducible)
+// lengths (ragged forms): frame m = b*T + t is valid iff t < lengths[b]; the other frames get score 0 (their row may not
+// have been computed at all).  offsets (compact form): the GEMM ran on the valid frames only, frame (b, t) is its row
+// offsets[b] + t; without offsets row(m) = m.
 __global__ void scorer_finish_kernel(const float* __restrict__ partial, int64_t ld, int ntiles,
-                                     const float* __restrict__ b2, int64_t N, const int32_t* __restrict__ lengths, int T,
-                                     float* __restrict__ scores) {
+                                     const float* __restrict__ b2, int64_t N, const int32_t* __restrict__ lengths,
+                                     const int32_t* __restrict__ offsets, int T, float* __restrict__ scores) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= N) return;
-    if (lengths && (int)(m % T) >= lengths[m / T]) {
-        scores[m] = 0.f;
-        return;
+    int64_t row = m;
+    if (lengths) {
+        const int b = (int)(m / T), t = (int)(m % T);
+        if (t >= lengths[b]) {
+            scores[m] = 0.f;
+            return;
+        }
+        if (offsets) row = (int64_t)offsets[b] + t;
     }
     float s = b2[0];
-    for (int t = 0; t < ntiles; ++t) s += partial[(int64_t)t * ld + m];
+    for (int t = 0; t < ntiles; ++t) s += partial[(int64_t)t * ld + row];
     scores[m] = s;
 }
 
@@ -618,15 +826,17 @@ __host__ __device__ static inline int relu_bit_pos(int64_t m, int n) {
     return 31 - ((int)((m >> 4) & 1) * 16 + ((n >> 4) & 3) * 4 + (int)(m & 3));
 }
 
-// G' = ds * relu'(H) for the R listed rows, from the forward's sign bits: G' row-major (the dX GEMM's A operand, only
-// when dX is wanted), G'^T (the dW1 GEMM's A operand), and per 64-row block the column sums c[n] = sum_r G'[r][n]
+// G' = ds * relu'(H) for the R listed rows, from the forward's sign bits: G' row-major (the A operand of the dX GEMM and
+// of the TN dW1 GEMM; NULL skips it), G'^T (the A operand of the NT dW1 GEMM; NULL skips it), and per 64-row block the
+// column sums c[n] = sum_r G'[r][n]
 // (fp32 ds, not the bf16 copy) and sum_r ds[r].  One workgroup = 64 rows x 128 columns (two wave columns of the
 // forward's tile: 2 x 64 B of bits per row, staged in LDS with the row's dscore).  Memory bound: 2 * Rpad * d * 2
 // bytes written, R * d / 8 * 8 read (a row's bits share their 64-byte lines with 7 other rows).
 constexpr int GB_ROWS = 64, GB_COLS = 128, GB_PITCH = 33;      // LDS dwords per row (32 + 1: bank spread)
 __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __restrict__ bits, int nbn,
                                                            const float* __restrict__ ds, const int32_t* __restrict__ rows,
-                                                           int R, int Rpad, int d, __bf16* __restrict__ G,
+                                                           const int32_t* __restrict__ bit_rows, int R, int Rpad, int d,
+                                                           __bf16* __restrict__ G,
                                                            __bf16* __restrict__ GT, float* __restrict__ colpart,
                                                            float* __restrict__ dspart) {
     __shared__ uint32_t brow[GB_ROWS * GB_PITCH];
@@ -634,18 +844,21 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
     __shared__ int bsh[GB_ROWS];                   // bit position of (row, tn = 0); tn lowers it by 4
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * GB_ROWS, n0 = blockIdx.y * GB_COLS;
+    // rows[r] = frame id (indexes ds); the forward's GEMM row of that frame (indexes the bits) is bit_rows[r] when the
+    // forward ran on a compacted frame list, the frame id itself otherwise
+    const int32_t* brows = bit_rows ? bit_rows : rows;
     if (tid < GB_ROWS) {
         const int r = r0 + tid;
         const int m = r < R ? rows[r] : 0;
         dsf[tid] = r < R ? ds[m] : 0.f;
-        bsh[tid] = relu_bit_pos(m, 0);
+        bsh[tid] = relu_bit_pos(r < R ? brows[r] : 0, 0);
     }
     {       // 128 B of bits per row: thread -> (row, 16-byte piece p of 8): wave column p / 4, lanes c = 4 (p % 4) .. +3
         const int row = tid >> 3, p8 = tid & 7;
         for (int rr = row; rr < GB_ROWS; rr += 32) {
             const int r = r0 + rr;
             u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-            if (r < R) v = *(const u32x4*)(bits + relu_bit_dword(rows[r], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
+            if (r < R) v = *(const u32x4*)(bits + relu_bit_dword(brows[r], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
             uint32_t* dstw = brow + rr * GB_PITCH + p8 * 4;
             dstw[0] = v[0];
             dstw[1] = v[1];
@@ -687,7 +900,7 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
             o[k] = on ? (__bf16)v : (__bf16)0.f;
             acc += on ? v : 0.f;
         }
-        *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
+        if (GT) *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -798,6 +1011,18 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     return STAR_OK;
 }
 
+static int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
+    static DevOnce once;
+    if (!reserve_lds_once(once, (const void*)gemm_tn_kernel, TN_LDS)) {
+        set_error("scorer GEMM: cannot reserve the kernel's LDS (hipFuncSetAttribute failed)");
+        return STAR_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(GEMM_THREADS), TN_LDS, st, p);
+    return STAR_OK;
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int bwd_splits(int d) {
@@ -856,13 +1081,15 @@ extern "C" size_t star_scorer_relu_bits_bytes(int64_t N, int d) {
 namespace star {
 static int scorer_fwd_impl(const char* who, const void* x, const void* w1, const float* b1, const float* w2,
                            const float* b2, int64_t N, int d, const int32_t* lengths, int T, const int32_t* live_tiles,
-                           int n_live, float* scores, void* relu_bits, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           int n_live, const int32_t* offsets, const int32_t* rows, int64_t n_rows, float* scores,
+                           void* relu_bits, void* workspace, size_t workspace_bytes, void* stream) {
     STAR_REQUIRE(x && w1 && b1 && w2 && b2 && scores && workspace, "%s: null pointer", who);
     STAR_REQUIRE(N >= 1 && N < (1ll << 31) - BM, "%s: bad N=%lld", who, (long long)N);
     STAR_REQUIRE(d >= 128 && d % 128 == 0, "%s: d=%d must be a multiple of 128", who, d);
-    if (workspace_bytes < star_scorer_fwd_workspace(N, d)) {
-        set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, star_scorer_fwd_workspace(N, d));
+    // M = the GEMM's rows: all N frames, or (compact form) the n_rows listed frames gathered through `rows`
+    const int64_t M = rows ? n_rows : N;
+    if (workspace_bytes < star_scorer_fwd_workspace(M, d)) {
+        set_error("%s: workspace %zu < %zu bytes", who, workspace_bytes, star_scorer_fwd_workspace(M, d));
         return STAR_ERR_WORKSPACE;
     }
     GemmParams p = {};
@@ -870,23 +1097,25 @@ static int scorer_fwd_impl(const char* who, const void* x, const void* w1, const
     p.B = (const __bf16*)w1;
     p.lda = d;
     p.ldb = d;
-    p.M = (int)N;
+    p.M = (int)M;
+    p.a_rows = rows;
+    p.a_rows_n = (int)(rows ? n_rows : 0);
     p.N = d;
     p.kchunks = d / BK;
     p.splits = 1;
     p.b1 = b1;
     p.w2 = w2;
     p.partial = (float*)workspace;
-    p.partial_ld = round_up(N, BM);
+    p.partial_ld = round_up(M > 0 ? M : 1, BM);
     STAR_REQUIRE(((uintptr_t)relu_bits & 15) == 0, "%s: relu_bits must be 16-byte aligned", who);
     p.relu_bits = (uint32_t*)relu_bits;
     p.live_tiles = live_tiles;
     p.n_live = n_live;
     hipStream_t st = (hipStream_t)stream;
-    if (!live_tiles || n_live > 0)
+    if (M > 0 && (!live_tiles || n_live > 0))
         if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;
     hipLaunchKernelGGL(scorer_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace,
-                       p.partial_ld, (d + BN - 1) / BN, b2, N, lengths, T, scores);
+                       p.partial_ld, (d + BN - 1) / BN, b2, N, lengths, offsets, T, scores);
     STAR_LAUNCH_CHECK(who);
     return STAR_OK;
 }
@@ -895,8 +1124,8 @@ static int scorer_fwd_impl(const char* who, const void* x, const void* w1, const
 extern "C" int star_scorer_fwd(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
                                int64_t N, int d, float* scores, void* relu_bits, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    return star::scorer_fwd_impl("star_scorer_fwd", x, w1, b1, w2, b2, N, d, nullptr, 1, nullptr, 0, scores, relu_bits,
-                                 workspace, workspace_bytes, stream);
+    return star::scorer_fwd_impl("star_scorer_fwd", x, w1, b1, w2, b2, N, d, nullptr, 1, nullptr, 0, nullptr, nullptr, 0,
+                                 scores, relu_bits, workspace, workspace_bytes, stream);
 }
 
 extern "C" int star_scorer_fwd_ragged(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
@@ -909,8 +1138,22 @@ extern "C" int star_scorer_fwd_ragged(const void* x, const void* w1, const float
     const int64_t N = (int64_t)B * T;
     STAR_REQUIRE(n_live >= 0 && n_live <= (N + BM - 1) / BM, "star_scorer_fwd_ragged: n_live=%d for %lld row tiles", n_live,
                  (long long)((N + BM - 1) / BM));
-    return scorer_fwd_impl("star_scorer_fwd_ragged", x, w1, b1, w2, b2, N, d, lengths, T, live_tiles, n_live, scores,
-                           relu_bits, workspace, workspace_bytes, stream);
+    return scorer_fwd_impl("star_scorer_fwd_ragged", x, w1, b1, w2, b2, N, d, lengths, T, live_tiles, n_live, nullptr,
+                           nullptr, 0, scores, relu_bits, workspace, workspace_bytes, stream);
+}
+
+extern "C" int star_scorer_fwd_compact(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
+                                       const int32_t* lengths, const int32_t* offsets, const int32_t* rows,
+                                       int64_t n_valid, int B, int T, int d, float* scores, void* relu_bits,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(lengths && offsets && rows, "star_scorer_fwd_compact: null pointer");
+    STAR_REQUIRE(B >= 1 && T >= 1, "star_scorer_fwd_compact: bad shape B=%d T=%d", B, T);
+    const int64_t N = (int64_t)B * T;
+    STAR_REQUIRE(n_valid >= 0 && n_valid <= N, "star_scorer_fwd_compact: n_valid=%lld of %lld frames", (long long)n_valid,
+                 (long long)N);
+    return scorer_fwd_impl("star_scorer_fwd_compact", x, w1, b1, w2, b2, N, d, lengths, T, nullptr, 0, offsets, rows,
+                           n_valid, scores, relu_bits, workspace, workspace_bytes, stream);
 }
 
 extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2,
@@ -937,6 +1180,19 @@ struct BwdLayout {
     int nblk, splits;
     size_t g_off, gt_off, xt_off, col_off, ds_off, slab_off, total;
 };
+// the TN dW1 GEMM parks the row ids of a workgroup's r range in LDS: usable while that range fits
+// (measured, tools/tn_rows_check.py: below ~16 k rows the two forms tie or NT wins by a few us -- its transposes run
+// beside the G' pass on the auxiliary stream and a workgroup's K loop is only a dozen tiles long; at 24 k rows TN is
+// 10-17 us faster, at 48 k rows 25-40 us)
+constexpr int64_t TN_MIN_ROWS = 16384;
+static bool bwd_use_tn(int64_t R, int d) {
+    const int ovr = test_override(STAR_OVR_SCORER_NT);             // 1 = NT, 2 = TN whenever it fits
+    if (ovr == 1) return false;
+    const int64_t kchunks = round_up(R, BM) / BK;
+    const int splits = bwd_splits(d);
+    if ((kchunks + splits - 1) / splits * BK > TN_MAX_ROWS) return false;
+    return ovr == 2 || R >= TN_MIN_ROWS;
+}
 static BwdLayout bwd_layout(int64_t R, int d, bool want_dx) {
     BwdLayout L;
     L.Rpad = round_up(R, BM);
@@ -972,6 +1228,16 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, 
                                int d, float* dw1, float* db1, float* dw2, float* db2, void* dx, int dx_zeroed,
                                void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
                                void* const* aux_events_host) {
+    return star_scorer_bwd_mapped(x, w1, w1ts, b1, w2, relu_bits, dscores, rows, nullptr, R, N, d, dw1, db1, dw2, db2, dx,
+                                  dx_zeroed, workspace, workspace_bytes, stream, aux_stream, aux_events_host);
+}
+
+extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void* w1ts, const float* b1, const float* w2,
+                                      const void* relu_bits, const float* dscores, const int32_t* rows,
+                                      const int32_t* bit_rows, int64_t R, int64_t N, int d, float* dw1, float* db1,
+                                      float* dw2, float* db2, void* dx, int dx_zeroed, void* workspace,
+                                      size_t workspace_bytes, void* stream, void* aux_stream,
+                                      void* const* aux_events_host) {
     using namespace star;
     STAR_REQUIRE(x && w1 && b1 && w2 && relu_bits && dscores && rows && dw1 && db1 && dw2 && db2 && workspace,
                  "star_scorer_bwd: null pointer");
@@ -984,11 +1250,14 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, 
         return STAR_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const BwdLayout L = bwd_layout(R, d, dx != nullptr);
+    // dW1 GEMM form: TN on the row-major G' and the gathered rows of x (no transposes), or -- for r ranges whose row
+    // ids do not fit the kernel's LDS -- NT on G'^T and X_sel^T
+    const bool tn = bwd_use_tn(R, d);
+    const BwdLayout L = bwd_layout(R, d, dx != nullptr || tn);
     const int64_t Rpad = L.Rpad;
     uint8_t* ws = (uint8_t*)workspace;
-    __bf16* G = dx ? (__bf16*)(ws + L.g_off) : nullptr;
-    __bf16* GT = (__bf16*)(ws + L.gt_off);
+    __bf16* G = (dx || tn) ? (__bf16*)(ws + L.g_off) : nullptr;
+    __bf16* GT = tn ? nullptr : (__bf16*)(ws + L.gt_off);
     __bf16* XT = (__bf16*)(ws + L.xt_off);
     float* colpart = (float*)(ws + L.col_off);
     float* dspart = (float*)(ws + L.ds_off);
@@ -1020,28 +1289,39 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, 
         STAR_HIP(hipEventRecord(ev_fork[0], st));
         STAR_HIP(hipStreamWaitEvent(aux, ev_fork[0], 0));
     }
-    // aux: dx zero-fill (rows that are not listed) and X_sel^T
+    // aux: dx zero-fill (rows that are not listed) and, for the NT form, X_sel^T
     if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
-    hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
-                       (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
+    if (!tn)
+        hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
+                           (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
     if (aux != st) STAR_HIP(hipEventRecord(ev_join[0], aux));
     // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials
     static_assert(GB_COLS == 128, "d is a multiple of 128");
     hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk, d / GB_COLS), dim3(256), 0, st, (const uint32_t*)relu_bits,
-                       (d + BN - 1) / BN, dscores, rows, (int)R, (int)Rpad, d, G, GT, colpart, dspart);
-    if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));
+                       (d + BN - 1) / BN, dscores, rows, bit_rows, (int)R, (int)Rpad, d, G, GT, colpart, dspart);
+    if (aux != st && !tn) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));     // X_sel^T is ready
     // 2. U = G'^T . X_sel  (split-K slabs)
     GemmParams q = {};
-    q.A = GT;
-    q.B = XT;
-    q.lda = Rpad;
-    q.ldb = Rpad;
     q.M = d;
     q.N = d;
     q.kchunks = (int)(Rpad / BK);
     q.splits = L.splits;
     q.slab = slab;
-    if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
+    if (tn) {
+        q.A = G;
+        q.B = (const __bf16*)x;
+        q.lda = d;
+        q.ldb = d;
+        q.a_rows = rows;            // here: the gather list of B's rows (r -> frame id)
+        q.a_rows_n = (int)R;
+        if (int rc = launch_gemm_tn(q, st)) return rc;
+    } else {
+        q.A = GT;
+        q.B = XT;
+        q.lda = Rpad;
+        q.ldb = Rpad;
+        if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
+    }
     // 3. reductions: dW1 = diag(w2) U, dw2, db1, db2 (on aux, beside the dX GEMM)
     if (aux != st) {
         STAR_HIP(hipEventRecord(ev_fork[1], st));
@@ -1053,6 +1333,7 @@ extern "C" int star_scorer_bwd(const void* x, const void* w1, const void* w1ts, 
     if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
     // 4. dX rows = G' . (diag(w2) W1)
     if (dx) {
+        if (aux != st && tn) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0)); // the zero-fill of dx is done
         GemmParams r = {};
         r.A = G;
         r.B = (const __bf16*)w1ts;

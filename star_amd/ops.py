@@ -594,15 +594,19 @@ def _aux_stream(dev):
 
 class ValidFrames:
     """Host-known lengths of a padded batch [B,T,...] prepared once for the ragged scorer: the device copy of the
-    lengths, the 256-row tiles of the flattened [B*T] frame axis that hold a valid frame (what star_scorer_fwd_ragged
-    computes) and the flat ids of the valid frames (the active rows of a backward that reaches every valid frame, as
-    the quantity loss does).  Built from a host list, so using it costs no device->host sync (HIP-graph safe)."""
+    lengths, the flat ids of the valid frames (the rows the compact forward gathers, and the active rows of a backward
+    that reaches every valid frame, as the quantity loss does), their exclusive prefix sums, the frame -> compact-row
+    table, and the 256-row tiles of the flattened [B*T] frame axis that hold a valid frame (what the tile form,
+    star_scorer_fwd_ragged, computes).  Built from a host list, so using it costs no device->host sync (HIP-graph
+    safe).  compact=True (default): the scorer GEMM runs on the valid frames only (star_scorer_fwd_compact);
+    compact=False: on the live 256-row tiles of the padded layout."""
 
     TILE = 256
 
-    def __init__(self, lengths: Sequence[int], T: int, device):
+    def __init__(self, lengths: Sequence[int], T: int, device, compact: bool = True):
         ln = np.minimum(np.asarray(list(lengths), dtype=np.int64), T)
         self.B, self.T = int(ln.size), int(T)
+        self.compact = bool(compact)
         starts = np.arange(self.B, dtype=np.int64) * T
         live = set()
         for b in range(self.B):
@@ -612,12 +616,27 @@ class ValidFrames:
         self.live_tiles = torch.tensor(sorted(live) or [0], dtype=torch.int32, device=device)
         self.n_live = len(live)
         rows = np.concatenate([starts[b] + np.arange(ln[b]) for b in range(self.B)]) if ln.sum() else np.zeros(0)
-        self.rows = torch.from_numpy(rows.astype(np.int32)).to(device)
-        self.lengths = torch.from_numpy(ln.astype(np.int32)).to(device)
         self.n_valid = int(ln.sum())
+        # (rows / arange keep one dummy entry for an all-padding batch, as live_tiles does)
+        self.rows = torch.from_numpy(rows.astype(np.int32)).to(device)
+        self._rows_ptr = torch.from_numpy((rows if self.n_valid else np.zeros(1)).astype(np.int32)).to(device)
+        self.lengths = torch.from_numpy(ln.astype(np.int32)).to(device)
+        offs = np.concatenate([[0], np.cumsum(ln)[:-1]])
+        self.offsets = torch.from_numpy(offs.astype(np.int32)).to(device)
+        # frame id -> row of the compacted list (pad frames -> row 0: they only ever carry a zero score gradient)
+        table = np.zeros(self.B * self.T, dtype=np.int32)
+        table[rows.astype(np.int64)] = np.arange(self.n_valid, dtype=np.int32)
+        self.row_of_frame = torch.from_numpy(table).to(device)
+        self.arange = torch.arange(max(self.n_valid, 1), dtype=torch.int32, device=device)[:self.n_valid]
 
     def matches(self, x) -> bool:
         return x.dim() == 3 and x.shape[0] == self.B and x.shape[1] == self.T
+
+    def bit_rows(self, rows):
+        """compact-list rows of the frames `rows` (int32 frame ids): where the compact forward left their ReLU bits"""
+        if rows is self.rows:
+            return self.arange
+        return self.row_of_frame[rows.long()]
 
 
 class _Scorer(torch.autograd.Function):
@@ -654,6 +673,11 @@ class _Scorer(torch.autograd.Function):
         if valid is None:
             check(lib().star_scorer_fwd(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), N, d, ptr(scores), ptr(bits),
                                         ptr(ws), wsb, stream_ptr()), "star_scorer_fwd")
+        elif valid.compact:
+            check(lib().star_scorer_fwd_compact(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), ptr(valid.lengths),
+                                                ptr(valid.offsets), ptr(valid._rows_ptr), valid.n_valid, valid.B, valid.T,
+                                                d, ptr(scores), ptr(bits), ptr(ws), wsb, stream_ptr()),
+                  "star_scorer_fwd_compact")
         else:
             check(lib().star_scorer_fwd_ragged(ptr(xb), ptr(w1b), ptr(b1f), ptr(w2f), ptr(b2f), ptr(valid.lengths),
                                                valid.B, valid.T, d, ptr(valid.live_tiles), valid.n_live, ptr(scores),
@@ -684,8 +708,17 @@ class _Scorer(torch.autograd.Function):
             # ragged forward: only valid frames have ReLU bits (and only they can carry a score gradient that matters:
             # pad scores are constants)
             rows = ctx.valid.rows if ctx.valid is not None else torch.arange(N, dtype=torch.int32, device=dev)
+        # the compact forward left the ReLU bits indexed by row of the valid-frame list, not by frame
+        bit_rows = ctx.valid.bit_rows(rows) if (ctx.valid is not None and ctx.valid.compact) else None
         rows = rows.to(torch.int32).contiguous().view(-1)
+        if bit_rows is not None:
+            bit_rows = bit_rows.to(torch.int32).contiguous().view(-1)
         R = rows.numel()
+        if R == 0:
+            z = lambda t, dt: torch.zeros(t, dtype=dt, device=dev)
+            t1, t2, t3, t4 = ctx.w_dtypes
+            gx = z(ctx.x_shape, ctx.x_dtype) if ctx.needs_input_grad[0] else None
+            return gx, z((d, d), t1), z((d,), t2), z(ctx.w2_shape, t3), z(ctx.b2_shape, t4), None, None
         need_dx = ctx.needs_input_grad[0] and w1ts is not None
         dx = torch.empty((N, d), dtype=torch.bfloat16, device=dev) if need_dx else None   # zero-filled by the call
         dw1 = torch.empty((d, d), dtype=torch.float32, device=dev)
@@ -697,10 +730,10 @@ class _Scorer(torch.autograd.Function):
         # the fork/join costs four event operations on the host: worth it when the launches are replayed from a HIP
         # graph (no host cost at replay), not for eager launches, which are host-bound already
         aux = _aux_stream(dev) if torch.cuda.is_current_stream_capturing() else None
-        check(lib().star_scorer_bwd(ptr(xb), ptr(w1b), ptr(w1ts), ptr(b1f), ptr(w2f), ptr(bits), ptr(ds), ptr(rows), R, N, d,
-                                    ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0, ptr(ws), wsb, stream_ptr(),
-                                    aux[0].cuda_stream if aux is not None else None,
-                                    aux[2] if aux is not None else None), "star_scorer_bwd")
+        check(lib().star_scorer_bwd_mapped(ptr(xb), ptr(w1b), ptr(w1ts), ptr(b1f), ptr(w2f), ptr(bits), ptr(ds), ptr(rows),
+                                           ptr(bit_rows), R, N, d, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), ptr(dx), 0,
+                                           ptr(ws), wsb, stream_ptr(), aux[0].cuda_stream if aux is not None else None,
+                                           aux[2] if aux is not None else None), "star_scorer_bwd_mapped")
         t1, t2, t3, t4 = ctx.w_dtypes
         gx = dx.view(ctx.x_shape).to(ctx.x_dtype) if need_dx else None
         return (gx, dw1.to(t1), db1.to(t2), dw2.view(ctx.w2_shape).to(t3), db2.view(ctx.b2_shape).to(t4), None, None)
@@ -708,8 +741,9 @@ class _Scorer(torch.autograd.Function):
 
 def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None, valid: Optional[ValidFrames] = None):
     """x [..., d] -> scores [...] fp32.  w1 [d,d] (nn.Linear layout), b1 [d], w2 [1,d], b2 [1].
-    valid (x [B,T,d] padded): pad frames get score 0 and all-padding row tiles are skipped (star_scorer_fwd_ragged);
-    the reference scores them and masks the result everywhere it is used."""
+    valid (x [B,T,d] padded): pad frames get score 0 and are not computed: the GEMM runs on the gathered valid frames
+    (star_scorer_fwd_compact) or, for ValidFrames(compact=False), on the 256-row tiles that hold a valid frame
+    (star_scorer_fwd_ragged); the reference scores them and masks the result everywhere it is used."""
     _need_cuda(x, w1, b1, w2, b2)
     return _Scorer.apply(x, w1, b1, w2, b2, hint, valid)
 
@@ -1117,4 +1151,4 @@ def test_override(which: int, value: int) -> int:
     return rc
 
 
-OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG, OVR_XA_FWD = 0, 1, 2, 3, 4
+OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG, OVR_XA_FWD, OVR_SCORER_NT = 0, 1, 2, 3, 4, 5

@@ -714,17 +714,21 @@ def test_streaming_segmenter_matches_offline(ops):
 
 
 # ------------------------------------------------------------------------------------------------ ragged scorer
-def test_ragged_scorer_equals_dense_on_valid_frames(ops):
-    """star_scorer_fwd_ragged skips row tiles that hold padding only and writes 0 at pad frames: scores at valid frames
-    and every gradient are bit-identical to the dense call with the same cotangent (zero at pad frames), for a dense
-    backward (quantity-loss-like) and for a backward with an active-row hint."""
+@pytest.mark.parametrize("compact", [True, False])
+def test_ragged_scorer_equals_dense_on_valid_frames(ops, compact):
+    """star_scorer_fwd_compact runs the GEMM on the gathered valid frames, star_scorer_fwd_ragged (compact=False) on
+    the row tiles that hold a valid frame; both write 0 at pad frames: scores at valid frames and every gradient are
+    bit-identical to the dense call with the same cotangent (zero at pad frames), for a dense backward
+    (quantity-loss-like) and for a backward with an active-row hint (which exercises the frame -> row map of the
+    ReLU bits in the compact form)."""
     from star_amd.nugget import NuggetScorer
     torch.manual_seed(4)
     B, T, d = 7, 700, 256
     lengths = [700, 13, 300, 0, 699, 257, 512]
-    valid = ops.ValidFrames(lengths, T, DEV)
+    valid = ops.ValidFrames(lengths, T, DEV, compact=compact)
     mask = torch.from_numpy(lmask(lengths, T)).to(DEV)
     assert valid.n_valid == sum(lengths) and valid.n_live < (B * T + 255) // 256
+    assert valid.offsets.tolist() == [0, 700, 713, 1013, 1013, 1712, 1969]
     sc = NuggetScorer(d).to(DEV)
     x = torch.randn(B, T, d, device=DEV).to(torch.bfloat16)
     g = torch.randn(B, T, device=DEV) * mask
@@ -754,9 +758,13 @@ def test_ragged_scorer_equals_dense_on_valid_frames(ops):
     with pytest.raises(ValueError):
         sc(x[:, :100], valid)
     # a batch without a single valid frame: nothing is computed, every score is 0
-    empty = ops.ValidFrames([0, 0], 300, DEV)
+    empty = ops.ValidFrames([0, 0], 300, DEV, compact=compact)
     with torch.no_grad():
         assert (sc(x[:2, :300].contiguous(), empty) == 0).all()
+    xe = x[:2, :300].contiguous().requires_grad_()
+    sc.zero_grad()
+    sc(xe, empty).sum().backward()
+    assert (xe.grad == 0).all() and all((p.grad == 0).all() for p in sc.parameters())
 
 
 # ------------------------------------------------------------------------------------------------ f-3, second half
@@ -1029,3 +1037,36 @@ def test_share_encoder_kv_same_kv_used_twice_and_generation_cache(ops):
             tok = torch.randn(B, 1, d, device=DEV).to(torch.bfloat16)
             for mm, kv in zip(mods, cache):
                 close(mm(tok, encoder_kv=kv)[0], mm(tok, encoder_hidden_states=enc)[0], "cached token", 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ TN dW1 GEMM
+@pytest.mark.parametrize("B,T,d,every", [(3, 500, 384, 1), (2, 1100, 1024, 3), (1, 77, 128, 1), (5, 640, 256, 7),
+                                         (12, 1500, 256, 1)])
+def test_scorer_backward_tn_gemm_equals_nt_gemm(ops, B, T, d, every):
+    """The scorer backward forms U = G'^T X_sel with the TN kernel straight from the row-major G' and the gathered rows
+    of x; the NT kernel on transposed copies (forced through star_test_override) is the reference: same operands, same
+    split and K-tile order -> the gradients agree to fp32 rounding (and are compared with the oracle elsewhere)."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(B * 1000 + d)
+    sc = NuggetScorer(d).to(DEV)
+    x = torch.randn(B, T, d, device=DEV).to(torch.bfloat16)
+    keep = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    keep[:, ::every] = True
+    g = torch.randn(B, T, device=DEV) * keep
+    rows = keep.view(-1).nonzero().view(-1).to(torch.int32)
+    res = []
+    for form in (2, 1):                                            # 2 = TN, 1 = NT (0 would pick by row count)
+        prev = ops.test_override(ops.OVR_SCORER_NT, form)
+        try:
+            xr = x.clone().requires_grad_()
+            sc.zero_grad()
+            s = sc(xr).squeeze(-1)
+            if every > 1:
+                sc.set_active_rows(rows)
+            s.backward(g)
+            res.append((xr.grad.clone(), [p.grad.clone() for p in sc.parameters()]))
+        finally:
+            ops.test_override(ops.OVR_SCORER_NT, prev)
+    assert torch.equal(res[0][0], res[1][0])                      # dX does not go through the dW1 GEMM
+    for a, b in zip(res[0][1], res[1][1]):
+        close(a, b, "scorer parameter gradient, TN vs NT", 1e-6)
