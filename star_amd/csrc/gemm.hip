@@ -527,13 +527,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    // blocks b and b+8 share an XCD: all column tiles of one (row panel, r split) run on one XCD (they share G' rows)
+    // blocks b and b+8 share an XCD (round-robin dispatch): ALL output tiles of one r split run on one XCD, so the G'
+    // and x rows of that split come out of HBM once and are shared through that XCD's L2 (every tile re-reads one of
+    // the two operand slabs: with the tiles of a split spread over the XCDs x left HBM nbm times)
     const int vb = blockIdx.x;
     const int xcd = vb & 7, local = vb >> 3;
-    const int panel = (local / nbn) * 8 + xcd;
-    const int n_tile = local % nbn;
-    if (panel >= nbm * p.splits) return;
-    const int m_tile = panel % nbm, split = panel / nbm;
+    const int tps = nbm * nbn;
+    const int split = (local / tps) * 8 + xcd;
+    if (split >= p.splits) return;
+    const int m_tile = (local % tps) / nbn, n_tile = local % nbn;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int cps = (p.kchunks + p.splits - 1) / p.splits;
     const int kc0 = split * cps;
@@ -1013,7 +1015,7 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
 
 static int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    const int grid = ((nbm * p.splits + 7) / 8) * 8 * nbn;
+    const int grid = 8 * nbm * nbn * ((p.splits + 7) / 8);           // every XCD gets whole r splits
     static DevOnce once;
     if (!reserve_lds_once(once, (const void*)gemm_tn_kernel, TN_LDS)) {
         set_error("scorer GEMM: cannot reserve the kernel's LDS (hipFuncSetAttribute failed)");
