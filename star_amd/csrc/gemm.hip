@@ -29,7 +29,8 @@
 
 #ifndef STAR_GEMM_ABL
 #define STAR_GEMM_ABL 0      // diagnostic builds (tools/build_abl.sh): 1 no DMA in the K loop, 2 no ds_reads, 4 no epilogue,
-                             // 8 every tile reads one of 8 cache-hot A panels
+                             // 8 every tile reads one of 8 cache-hot A panels; TN kernel: 1, 2, 16 one ds_read_b128 in
+                             // place of each pair of transposing reads, 64 no slab store
 #endif
 
 namespace star {
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
 
 #define STAR_TN_STAGE_A(H, TT)                                                                               \
     do {                                                                                                     \
+        if ((STAR_GEMM_ABL & 1) && tn_in_loop) break;                                                        \
         if ((TT) < nk) {                                                                                     \
             uint8_t* dst_ = lds + ((TT) & 1) * BUF_BYTES + ((H) ? H_A1 : H_A0) * HALF_BYTES + wid * 2048;     \
             glds16(asrc[H][0] + (int64_t)(TT) * BK * p.lda, dst_);                                           \
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     } while (0)
 #define STAR_TN_STAGE_B(H, TT, R0, R1)                                                                       \
     do {                                                                                                     \
+        if ((STAR_GEMM_ABL & 1) && tn_in_loop) break;                                                        \
         if ((TT) < nk) {                                                                                     \
             uint8_t* dst_ = lds + ((TT) & 1) * BUF_BYTES + ((H) ? H_B1 : H_B0) * HALF_BYTES + wid * 2048;     \
             glds16(p.B + (int64_t)(R0) * p.ldb + bcol[H][0], dst_);                                          \
@@ -601,11 +604,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     const int rbase = (8 * g4 + (i16 >> 2)) * 256 + 8 * (i16 & 3);
     bf16x8 af[4][2], bfr[2][2][2];
     auto tr8 = [&](const uint8_t* q) -> bf16x8 {
+        if (STAR_GEMM_ABL & 16) return *(const bf16x8*)(q - 8 * (i16 & 1));      // diagnostic: one 16-byte read
         bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
         bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * 256));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+    if (STAR_GEMM_ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][0] = af[i][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[i][j][0] = bfr[i][j][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+    }
     auto read_a = [&](int buf, int mh) {
+        if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + rbase;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -615,6 +628,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
         }
     };
     auto read_b = [&](int buf, int nh) {
+        if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + (nh ? H_B1 : H_B0) * HALF_BYTES + rbase;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -639,6 +653,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
 
+    bool tn_in_loop = false;
+    (void)tn_in_loop;
     if (nk > 0) {
         // prologue: all of K tile 0 and three half-tiles of K tile 1 (seven half-tiles ahead, as in the loop).  The G'
         // halves of tile 0 go first (they need no row id); the row ids of tiles 0 and 1 are loaded by the staging
@@ -660,6 +676,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
 
         if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave row runs one barrier behind the first
         __builtin_amdgcn_sched_barrier(0);
+        tn_in_loop = true;
         for (int t = 0; t < nk; ++t) {
             const int buf = t & 1;
             const int n0r = row_id(t + 2, 0), n1r = row_id(t + 2, 1);     // rows of K tile t + 2
@@ -703,7 +720,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int m = m0 + (tm >> 2) * 128 + wr * 64 + (tm & 3) * 16 + crow4 + j;
                 const int n = n0 + (tn >> 1) * 128 + wc * 32 + (tn & 1) * 16 + ccol;
-                if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
+                if ((STAR_GEMM_ABL & 64) ? acc[tm][tn][j] == 123.456f : (m < p.M && n < p.N))
+                    slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
             }
 }
 
