@@ -302,6 +302,8 @@ int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const
  * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),
  *   dx [N,d] bf16 or NULL: rows listed in rows[] are written; all other rows are zero-filled by the call
  *   unless dx_zeroed != 0 says the caller has done so already.
+ * dW1 GEMM: from 16384 rows up a TN kernel reads G' and the listed rows of x in place; below that an NT kernel runs on
+ *   transposed copies (G'^T from the G' pass, X_sel^T from a gather-transpose pass) -- same results up to fp32 rounding.
  * aux_stream (may be NULL): a second stream of the same device.  When given, the memory-bound helpers of the
  *   call (dx zero-fill, X_sel^T, the split-K / column reductions) run on it beside the GEMMs; the call forks from
  *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
