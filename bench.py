@@ -463,6 +463,31 @@ def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg):
         ilk = -1
         kb = np.asarray(ops.nugget_counts_host(inp.lengths, rate), dtype=np.float64)
         lq = np.full(B, float(L))
+    # scorer backward (G' pass, dW1 GEMM + reductions, dX GEMM) on the rows the step's backward reaches
+    xs = inp.x.detach().clone().requires_grad_(not simul)      # the simultaneous model scores detached encoder states
+    sfull = scorer(xs, inp.valid).squeeze(-1)
+    if simul:
+        rows = inp.valid.rows if inp.valid is not None else torch.arange(B * T, dtype=torch.int32, device=dev)
+    else:
+        rows = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K, want_rows=True)[-1]
+    gsc = torch.zeros(B * T, device=dev)
+    gsc[rows.long()] = torch.randn(rows.numel(), device=dev)
+    gsc = gsc.view(B, T)
+    params = list(scorer.parameters())
+
+    def scorer_bwd():
+        scorer.set_active_rows(rows)                 # single-use hint, as in the step
+        return torch.autograd.grad(sfull, ([] if simul else [xs]) + params, gsc, retain_graph=True)
+    us = event_time_us(scorer_bwd)
+    R = float(rows.numel())
+    if simul:
+        leg("scorer backward over the valid frames (G' pass, dW1 GEMM + reductions)",
+            "scorer_bwd_g_kernel, gemm_tn_kernel | gemm_nt_kernel<EPI_SLAB>, scorer_bwd_finish_kernel",
+            us, flops=R * (2.0 * d * d + 4.0 * d), bytes_=2.0 * d * R + 3 * 4.0 * d * d)
+    else:
+        leg("scorer backward over the selected frames (G' pass, dW1 GEMM + reductions, dX GEMM)",
+            "scorer_bwd_g_kernel, gemm_tn_kernel | gemm_nt_kernel<EPI_SLAB>, gemm_nt_kernel<EPI_ROWS>, scorer_bwd_finish_kernel",
+            us, flops=R * (4.0 * d * d + 4.0 * d), bytes_=2.0 * d * R * 2 + 2.0 * d * B * T + 3 * 4.0 * d * d)
     sg = ops.gather_rows(scores, idx)
     s_det = inp.s.detach()
     us = event_time_us(lambda: ops.gather_rows(s_det, idx))
