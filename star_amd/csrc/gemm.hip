@@ -546,7 +546,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     // row ids of this workgroup's r range (rows past the list repeat entry 0: their G' rows are zero): parked in LDS
     // behind the ring -- after the prologue's DMA is on its way, see below
     int* rows_lds = (int*)(lds + GEMM_LDS);
-    auto gathered = [&](int r) { return p.a_rows ? p.a_rows[r < p.a_rows_n ? r : 0] : min(r, p.a_rows_n - 1); };
+    auto gathered = [&](int r) { return p.a_rows[r < p.a_rows_n ? r : 0]; };
 
     // staging geometry: wave w stages pieces 2w, 2w+1 (4 rows x 256 B each) of every half-tile; lane l -> row
     // piece*4 + (l >> 4), LDS chunk position l & 15, source chunk = the same position with its 32-byte window XOR-ed
@@ -1034,6 +1034,10 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
 static int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int grid = 8 * nbm * nbn * ((p.splits + 7) / 8);           // every XCD gets whole r splits
+    if (!p.a_rows || p.a_rows_n < 1) {
+        set_error("scorer GEMM (TN): the row list of x is required");
+        return STAR_ERR_ARG;
+    }
     static DevOnce once;
     if (!reserve_lds_once(once, (const void*)gemm_tn_kernel, TN_LDS)) {
         set_error("scorer GEMM: cannot reserve the kernel's LDS (hipFuncSetAttribute failed)");

@@ -619,7 +619,7 @@ class ValidFrames:
         self.n_valid = int(ln.sum())
         # (rows / arange keep one dummy entry for an all-padding batch, as live_tiles does)
         self.rows = torch.from_numpy(rows.astype(np.int32)).to(device)
-        self._rows_ptr = torch.from_numpy((rows if self.n_valid else np.zeros(1)).astype(np.int32)).to(device)
+        self._rows_ptr = self.rows if self.n_valid else torch.zeros(1, dtype=torch.int32, device=device)
         self.lengths = torch.from_numpy(ln.astype(np.int32)).to(device)
         offs = np.concatenate([[0], np.cumsum(ln)[:-1]])
         self.offsets = torch.from_numpy(offs.astype(np.int32)).to(device)
