@@ -304,8 +304,8 @@ int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const
  *   unless dx_zeroed != 0 says the caller has done so already.
  * dW1 GEMM: from 16384 rows up a TN kernel reads G' and the listed rows of x in place; below that an NT kernel runs on
  *   transposed copies (G'^T from the G' pass, X_sel^T from a gather-transpose pass) -- same results up to fp32 rounding.
- * aux_stream (may be NULL): a second stream of the same device.  When given, the memory-bound helpers of the
- *   call (dx zero-fill, X_sel^T, the split-K / column reductions) run on it beside the GEMMs; the call forks from
+ * aux_stream (may be NULL): a second stream of the same device.  When given, X_sel^T (NT form), the zero-fill of dx
+ *   and the dX GEMM run on it beside the G' pass, the dW1 GEMM and the reductions; the call forks from
  *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
  *   `stream` captures both branches).
  * aux_events_host: HOST array of four hipEvent_t created by the caller (hipEventDisableTiming suffices), required

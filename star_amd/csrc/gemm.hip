@@ -1287,8 +1287,8 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
     float* dspart = (float*)(ws + L.ds_off);
     float* slab = (float*)(ws + L.slab_off);
 
-    // Two independent chains: the MFMA-bound GEMMs stay on `stream`; the memory-bound helpers (zero-fill of dx,
-    // X_sel^T, the slab / column reductions) run beside them on `aux_stream` when the caller provides one.
+    // Two chains when the caller provides `aux_stream`: G' pass, dW1 GEMM and the slab / column reductions on `stream`;
+    // X_sel^T (NT form), the zero-fill of dx and the dX GEMM on `aux_stream`.
     hipStream_t aux = aux_stream ? (hipStream_t)aux_stream : st;
     // fork / join events belong to the caller (one set per stream pair): the library keeps no event of its own
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -1313,12 +1313,13 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         STAR_HIP(hipEventRecord(ev_fork[0], st));
         STAR_HIP(hipStreamWaitEvent(aux, ev_fork[0], 0));
     }
-    // aux: dx zero-fill (rows that are not listed) and, for the NT form, X_sel^T
-    if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
+    // aux: X_sel^T for the NT form first (the dW1 GEMM waits for it), then the zero-fill of dx (rows that are not
+    // listed), which only the dX GEMM -- issued on aux behind it -- needs
     if (!tn)
         hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
                            (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
-    if (aux != st) STAR_HIP(hipEventRecord(ev_join[0], aux));
+    if (aux != st && !tn) STAR_HIP(hipEventRecord(ev_join[0], aux));
+    if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
     // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials
     static_assert(GB_COLS == 128, "d is a multiple of 128");
     hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk, d / GB_COLS), dim3(256), 0, st, (const uint32_t*)relu_bits,
@@ -1346,18 +1347,13 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         q.ldb = Rpad;
         if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
     }
-    // 3. reductions: dW1 = diag(w2) U, dw2, db1, db2 (on aux, beside the dX GEMM)
+    // 3. dX rows = G' . (diag(w2) W1) on aux (behind the zero-fill of dx), beside
+    // 4. the reductions on the main stream: dW1 = diag(w2) U, dw2, db1, db2
     if (aux != st) {
         STAR_HIP(hipEventRecord(ev_fork[1], st));
         STAR_HIP(hipStreamWaitEvent(aux, ev_fork[1], 0));
     }
-    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(d), dim3(256), 0, aux, (const float*)slab, L.splits, d,
-                       (const __bf16*)w1, b1, w2, (const float*)colpart, (const float*)dspart, L.nblk, dw1, dw2, db1,
-                       db2);
-    if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
-    // 4. dX rows = G' . (diag(w2) W1)
     if (dx) {
-        if (aux != st && tn) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0)); // the zero-fill of dx is done
         GemmParams r = {};
         r.A = G;
         r.B = (const __bf16*)w1ts;
@@ -1371,8 +1367,12 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         r.ldo = d;
         r.out_rows = rows;
         r.out_rows_n = (int)R;
-        if (int rc = launch_gemm(EPI_ROWS, r, st)) return rc;
+        if (int rc = launch_gemm(EPI_ROWS, r, aux)) return rc;
     }
+    if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
+    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(d), dim3(256), 0, st, (const float*)slab, L.splits, d,
+                       (const __bf16*)w1, b1, w2, (const float*)colpart, (const float*)dspart, L.nblk, dw1, dw2, db1,
+                       db2);
     if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[1], 0));
 #undef STAR_HIP
     STAR_LAUNCH_CHECK("star_scorer_bwd");

@@ -1072,3 +1072,46 @@ def test_scorer_backward_tn_gemm_equals_nt_gemm(ops, B, T, d, every):
     assert torch.equal(res[0][0], res[1][0])                      # dX does not go through the dW1 GEMM
     for a, b in zip(res[0][1], res[1][1]):
         close(a, b, "scorer parameter gradient, TN vs NT", 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ graph capture
+@pytest.mark.parametrize("form,every", [(1, 4), (2, 1), (2, 4)])
+def test_scorer_backward_under_graph_capture_equals_eager(ops, form, every):
+    """Captured in a HIP graph, star_scorer_bwd forks onto the auxiliary stream (X_sel^T, the zero-fill of dx and the
+    dX GEMM beside the G' pass / dW1 GEMM / reductions); eager launches use one stream.  Same kernels on the same
+    operands: every gradient must come out bit-identical, and replaying the graph must reproduce them (dx is re-zeroed
+    and re-written by every replay).  form: 1 = NT dW1 GEMM, 2 = TN."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(31)
+    B, T, d = 4, 600, 256
+    sc = NuggetScorer(d).to(DEV)
+    x = torch.randn(B, T, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    keep = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    keep[:, ::every] = True
+    g = torch.randn(B, T, device=DEV) * keep
+    rows = keep.view(-1).nonzero().view(-1).to(torch.int32)
+    params = list(sc.parameters())
+    prev = ops.test_override(ops.OVR_SCORER_NT, form)
+    stream = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(stream):
+            def step():
+                s = sc(x).squeeze(-1)
+                sc.set_active_rows(rows)
+                return torch.autograd.grad(s, [x] + params, g)
+            eager = [t.clone() for t in step()]
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                outs = step()
+            for _ in range(3):
+                for o in outs:
+                    o.fill_(float("nan"))
+                graph.replay()
+                torch.cuda.synchronize()
+                for a, b in zip(outs, eager):
+                    assert torch.equal(a, b)
+    finally:
+        ops.test_override(ops.OVR_SCORER_NT, prev)
