@@ -464,8 +464,10 @@ def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg):
         kb = np.asarray(ops.nugget_counts_host(inp.lengths, rate), dtype=np.float64)
         lq = np.full(B, float(L))
     # scorer backward (G' pass, dW1 GEMM + reductions, dX GEMM) on the rows the step's backward reaches
+    import copy
+    scorer_leg_mod = copy.deepcopy(scorer)     # fresh leaves: the step's parameters carry AccumulateGrad nodes of its stream
     xs = inp.x.detach().clone().requires_grad_(not simul)      # the simultaneous model scores detached encoder states
-    sfull = scorer(xs, inp.valid).squeeze(-1)
+    sfull = scorer_leg_mod(xs, inp.valid).squeeze(-1)
     if simul:
         rows = inp.valid.rows if inp.valid is not None else torch.arange(B * T, dtype=torch.int32, device=dev)
     else:
@@ -473,10 +475,10 @@ def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg):
     gsc = torch.zeros(B * T, device=dev)
     gsc[rows.long()] = torch.randn(rows.numel(), device=dev)
     gsc = gsc.view(B, T)
-    params = list(scorer.parameters())
+    params = list(scorer_leg_mod.parameters())
 
     def scorer_bwd():
-        scorer.set_active_rows(rows)                 # single-use hint, as in the step
+        scorer_leg_mod.set_active_rows(rows)         # single-use hint, as in the step
         return torch.autograd.grad(sfull, ([] if simul else [xs]) + params, gsc, retain_graph=True)
     us = event_time_us(scorer_bwd)
     R = float(rows.numel())
