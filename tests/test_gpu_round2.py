@@ -1115,3 +1115,33 @@ def test_scorer_backward_under_graph_capture_equals_eager(ops, form, every):
                     assert torch.equal(a, b)
     finally:
         ops.test_override(ops.OVR_SCORER_NT, prev)
+
+
+def test_scorer_backward_tn_row_range_limit(ops):
+    """The TN dW1 GEMM keeps the row ids of a workgroup's r range in LDS (7168 ids): R = 114 688 rows at 16 splits is the
+    largest case it takes, one more 256-row block goes to the NT form.  Both sides of the limit against the forced NT
+    form on the same rows."""
+    from star_amd.nugget import NuggetScorer
+    torch.manual_seed(41)
+    B, T, d = 77, 1500, 128
+    sc = NuggetScorer(d).to(DEV)
+    x = torch.randn(B, T, d, device=DEV).to(torch.bfloat16)
+    g_full = torch.randn(B, T, device=DEV)
+    for R in (114688, 114688 + 256):
+        rows = torch.arange(R, dtype=torch.int32, device=DEV)
+        g = g_full.clone().view(-1)
+        g[R:] = 0
+        g = g.view(B, T)
+        res = []
+        for form in (0, 1):                                            # 0 = the library's choice, 1 = NT
+            prev = ops.test_override(ops.OVR_SCORER_NT, form)
+            try:
+                sc.zero_grad()
+                s = sc(x).squeeze(-1)
+                sc.set_active_rows(rows)
+                s.backward(g)
+                res.append([p.grad.clone() for p in sc.parameters()])
+            finally:
+                ops.test_override(ops.OVR_SCORER_NT, prev)
+        for a, b in zip(*res):
+            close(a, b, f"scorer parameter gradient at R = {R}", 1e-6)
