@@ -12,6 +12,10 @@
 //               which are all the backward needs of H: there is no recompute GEMM)               (forward)
 //   EPI_SLAB    fp32 split-K slab store                                      (U = G'^T X_sel, G' = ds * relu'(H))
 //   EPI_ROWS    bf16 store with row scatter                                  (dX = G' (diag(w2) W1))
+// From 16384 backward rows up U comes from gemm_tn_kernel instead, which reads G' and the listed rows of X as they lie
+// (both row-major by the reduction index; fragments by transposing LDS reads) and so needs no G'^T / X_sel^T copies.
+// Padded batches: the forward gathers the valid frames through a row list (star_scorer_fwd_compact) or skips the row
+// tiles without a valid frame (star_scorer_fwd_ragged).
 // Tile 256x256x64, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
 // registers).  Operands are staged with global_load_lds (16 B/lane, LDS image lane-linear) into two LDS buffers
 // of four 16-KiB half-tiles each (128 KiB).  A K tile is consumed in four phases, one accumulator quadrant
