@@ -46,8 +46,8 @@ const char* star_last_error(void);
 #define STAR_OVR_XA_DKV 2  /* 1 = the general dK/dV kernel */
 #define STAR_OVR_XA_NG 3   /* key groups of the register-staged attention forward / general dQ: 1 or 2 */
 #define STAR_OVR_XA_FWD 4  /* attention forward: 1 = the register-staged kernel instead of the LDS-DMA ring */
-#define STAR_OVR_SCORER_NT 5 /* scorer backward dW1 GEMM: 1 = NT on transposed copies, 2 = TN on the row-major operands
-                              (0: TN from 16384 rows up) */
+#define STAR_OVR_SCORER_NT 5 /* scorer backward dW1 GEMM: 1 = NT on transposed copies (0 / 2: TN on the row-major
+                              operands wherever a workgroup's row ids fit its LDS) */
 #define STAR_OVR_COUNT 6
 int star_test_override(int which, int value);
 
@@ -302,8 +302,9 @@ int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const
  * Outputs: dw1 [d,d] fp32, db1 [d] fp32, dw2 [d] fp32, db2 [1] fp32 (all overwritten),
  *   dx [N,d] bf16 or NULL: rows listed in rows[] are written; all other rows are zero-filled by the call
  *   unless dx_zeroed != 0 says the caller has done so already.
- * dW1 GEMM: from 16384 rows up a TN kernel reads G' and the listed rows of x in place; below that an NT kernel runs on
- *   transposed copies (G'^T from the G' pass, X_sel^T from a gather-transpose pass) -- same results up to fp32 rounding.
+ * dW1 GEMM: a TN kernel reads G' and the listed rows of x in place; beyond 114688 rows (d <= 1024: 16 K splits) an NT
+ *   kernel runs on transposed copies (G'^T from the G' pass, X_sel^T from a gather-transpose pass) -- same results up
+ *   to fp32 rounding.
  * aux_stream (may be NULL): a second stream of the same device.  When given, X_sel^T (NT form), the zero-fill of dx
  *   and the dX GEMM run on it beside the G' pass, the dW1 GEMM and the reductions; the call forks from
  *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of

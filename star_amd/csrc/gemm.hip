@@ -12,8 +12,9 @@
 //               which are all the backward needs of H: there is no recompute GEMM)               (forward)
 //   EPI_SLAB    fp32 split-K slab store                                      (U = G'^T X_sel, G' = ds * relu'(H))
 //   EPI_ROWS    bf16 store with row scatter                                  (dX = G' (diag(w2) W1))
-// From 16384 backward rows up U comes from gemm_tn_kernel instead, which reads G' and the listed rows of X as they lie
-// (both row-major by the reduction index; fragments by transposing LDS reads) and so needs no G'^T / X_sel^T copies.
+// U comes from gemm_tn_kernel, which reads G' and the listed rows of X as they lie
+// (both row-major by the reduction index; fragments by transposing LDS reads) and so needs no G'^T / X_sel^T copies;
+// EPI_SLAB on those copies remains for row counts whose row ids do not fit the TN kernel's LDS (> 114688 rows at 16 splits).
 // Padded batches: the forward gathers the valid frames through a row list (star_scorer_fwd_compact) or skips the row
 // tiles without a valid frame (star_scorer_fwd_ragged).
 // Tile 256x256x64, 512 threads = 8 waves (2x4), each wave 128x64 = 8x4 mfma_f32_16x16x32_bf16 (128 accumulator
@@ -33,8 +34,8 @@
 
 #ifndef STAR_GEMM_ABL
 #define STAR_GEMM_ABL 0      // diagnostic builds (tools/build_abl.sh): 1 no DMA in the K loop, 2 no ds_reads, 4 no epilogue,
-                             // 8 every tile reads one of 8 cache-hot A panels; TN kernel: 1, 2, 16 one ds_read_b128 in
-                             // place of each pair of transposing reads, 64 no slab store
+                             // 8 every tile reads one of 8 cache-hot A panels; TN kernel: 1, 2, 64 no slab store (16, one
+                             // ds_read_b128 in place of each pair of transposing reads, existed in the builtin version)
 #endif
 
 namespace star {
@@ -316,11 +317,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     auto read_a = [&](int buf, int mh) {
         if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + a_off;
+        // k-step-major: the MFMA block starts with the ks = 0 products, whose fragments are then the first to arrive
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff0);
-            af[i][1] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff1);
-        }
+        for (int i = 0; i < 4; ++i) af[i][0] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i][1] = *(const bf16x8*)(base + i * 16 * ROW_BYTES + choff1);
     };
     auto read_b0 = [&](int buf) {
         if (STAR_GEMM_ABL & 2) return;
@@ -606,29 +607,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     const int i16 = lane & 15, g4 = lane >> 4;
     const int key = (i16 >> 2) | ((g4 & 1) << 2);
     const int rbase = (8 * g4 + (i16 >> 2)) * 256 + 8 * (i16 & 3);
-    bf16x8 af[4][2], bfr[2][2][2];
-    auto tr8 = [&](const uint8_t* q) -> bf16x8 {
-        if (STAR_GEMM_ABL & 16) return *(const bf16x8*)(q - 8 * (i16 & 1));      // diagnostic: one 16-byte read
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, q + 4 * 256));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    // The reads are inline asm: the ds_read_tr builtin has no memory operand, so next to an LDS-DMA in flight hipcc drains
+    // vmcnt(0) before every group of them -- which emptied the seven-half-tile DMA pipeline four times per K tile (the
+    // first version of this kernel: 123 us at R = 48000).  Asm reads are not tracked at all: the halves stay in
+    // separate registers until STAR_TN_MMA has waited for lgkmcnt(0).
+    bf16x4 afl[4][2], afh[4][2], bfl[2][2][2], bfh[2][2][2];
+#define STAR_TN_TR(LO, HI, ADDR, OFF)                                                                        \
+    do {                                                                                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(LO) : "v"(ADDR), "n"(OFF));                \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(HI) : "v"(ADDR), "n"((OFF) + 4 * 256));    \
+    } while (0)
+    auto lds_addr32 = [](const uint8_t* q) {
+        return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)q;
     };
     if (STAR_GEMM_ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i][0] = af[i][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) afl[i][ks] = afh[i][ks] = (bf16x4){1, 1, 1, 1};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[i][j][0] = bfr[i][j][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bfl[i][j][ks] = bfh[i][j][ks] = (bf16x4){1, 1, 1, 1};
     }
     auto read_a = [&](int buf, int mh) {
         if (STAR_GEMM_ABL & 2) return;
         const uint8_t* base = lds + buf * BUF_BYTES + (mh ? H_A1 : H_A0) * HALF_BYTES + rbase;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int off = ((wr * 4 + i) ^ key) << 5;
-            af[i][0] = tr8(base + off);
-            af[i][1] = tr8(base + 32 * 256 + off);
+            const uint32_t ad = lds_addr32(base + (((wr * 4 + i) ^ key) << 5));
+            STAR_TN_TR(afl[i][0], afh[i][0], ad, 0);
+            STAR_TN_TR(afl[i][1], afh[i][1], ad, 32 * 256);
         }
     };
     auto read_b = [&](int buf, int nh) {
@@ -636,21 +647,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
         const uint8_t* base = lds + buf * BUF_BYTES + (nh ? H_B1 : H_B0) * HALF_BYTES + rbase;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int off = ((wc * 2 + j) ^ key) << 5;
-            bfr[nh][j][0] = tr8(base + off);
-            bfr[nh][j][1] = tr8(base + 32 * 256 + off);
+            const uint32_t ad = lds_addr32(base + (((wc * 2 + j) ^ key) << 5));
+            STAR_TN_TR(bfl[nh][j][0], bfh[nh][j][0], ad, 0);
+            STAR_TN_TR(bfl[nh][j][1], bfh[nh][j][1], ad, 32 * 256);
         }
     };
+#define STAR_TN_F8(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
 #define STAR_TN_MMA(MH, NH)                                                                                  \
     do {                                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* the untracked fragment reads */       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
                     acc[4 * (MH) + i][2 * (NH) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(               \
-                        af[i][ks], bfr[NH][j][ks], acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0);                \
+                        STAR_TN_F8(afl[i][ks], afh[i][ks]), STAR_TN_F8(bfl[NH][j][ks], bfh[NH][j][ks]),      \
+                        acc[4 * (MH) + i][2 * (NH) + j], 0, 0, 0);                                           \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_barrier();                                                                        \
@@ -712,6 +726,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
 #undef STAR_TN_STAGE_A
 #undef STAR_TN_STAGE_B
 #undef STAR_TN_MMA
+#undef STAR_TN_F8
+#undef STAR_TN_TR
 
     // fp32 split slab: C layout of mfma_f32_16x16x32 is col = lane & 15, row = (lane >> 4) * 4 + j
     const int ccol = lane & 15, crow4 = (lane >> 4) * 4;
@@ -1209,17 +1225,13 @@ struct BwdLayout {
     size_t g_off, gt_off, xt_off, col_off, ds_off, slab_off, total;
 };
 // the TN dW1 GEMM parks the row ids of a workgroup's r range in LDS: usable while that range fits
-// (measured, tools/tn_rows_check.py: below ~16 k rows the two forms tie or NT wins by a few us -- its transposes run
-// beside the G' pass on the auxiliary stream and a workgroup's K loop is only a dozen tiles long; at 24 k rows TN is
-// 10-17 us faster, at 48 k rows 25-40 us)
-constexpr int64_t TN_MIN_ROWS = 16384;
+// (measured, tools/tn_rows_check.py, 3 k - 48 k rows, scattered and contiguous: TN is 4-9 us faster up to 12 k rows,
+// 20-60 us faster at 24 k - 48 k)
 static bool bwd_use_tn(int64_t R, int d) {
-    const int ovr = test_override(STAR_OVR_SCORER_NT);             // 1 = NT, 2 = TN whenever it fits
-    if (ovr == 1) return false;
+    if (test_override(STAR_OVR_SCORER_NT) == 1) return false;      // 1 = NT (2 = TN: the default wherever it fits)
     const int64_t kchunks = round_up(R, BM) / BK;
     const int splits = bwd_splits(d);
-    if ((kchunks + splits - 1) / splits * BK > TN_MAX_ROWS) return false;
-    return ovr == 2 || R >= TN_MIN_ROWS;
+    return (kchunks + splits - 1) / splits * BK <= TN_MAX_ROWS;
 }
 static BwdLayout bwd_layout(int64_t R, int d, bool want_dx) {
     BwdLayout L;

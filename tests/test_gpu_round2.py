@@ -1057,7 +1057,7 @@ def test_scorer_backward_tn_gemm_equals_nt_gemm(ops, B, T, d, every):
     g = torch.randn(B, T, device=DEV) * keep
     rows = keep.view(-1).nonzero().view(-1).to(torch.int32)
     res = []
-    for form in (2, 1):                                            # 2 = TN, 1 = NT (0 would pick by row count)
+    for form in (2, 1):                                            # 2 = TN (the default), 1 = NT
         prev = ops.test_override(ops.OVR_SCORER_NT, form)
         try:
             xr = x.clone().requires_grad_()

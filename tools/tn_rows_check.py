@@ -12,7 +12,7 @@ st = torch.cuda.Stream(); torch.cuda.set_stream(st)
 T, d = 1500, 1024
 torch.manual_seed(0)
 sc = NuggetScorer(d).to(dev)
-cases = [(32, 4, False), (32, 4, True), (64, 4, False), (64, 4, True), (128, 4, False), (128, 4, True), (16, 1, True),
+cases = [(32, 12, False), (32, 8, False), (8, 4, False), (32, 4, False), (32, 4, True), (64, 4, False), (64, 4, True), (128, 4, False), (128, 4, True), (16, 1, True),
          (32, 1, True), (32, 2, False), (32, 2, True)]
 for B, every, run in cases:
     x = torch.randn(B, T, d, device=dev).bfloat16().requires_grad_()
