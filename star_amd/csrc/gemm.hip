@@ -131,8 +131,13 @@ __device__ __forceinline__ u32x4 ep_read_mrow(const uint8_t* W, int mb, int nh, 
 // per-column-tile partial scores, and the ReLU sign bits.  Persistent mode: the next tile's operands are landing in
 // the ring right now, so the row reduction has its own LDS behind it and uses raw barriers (a __syncthreads() would
 // drain the DMA queue).
+// BW_STAGED: b1 / w2 come from the copy behind the ring.  They are read by inline asm: to hipcc a plain LDS load may
+// alias the LDS-DMA in flight (the next tile's operands) and gets an s_waitcnt vmcnt(0) in front of it, and a runtime
+// choice between the LDS copy and global loads ends in the same wait at the join -- either drains, at the start of
+// every epilogue, the prologue that the persistent loop has just put in flight behind it.
+template <bool BW_STAGED>
 __device__ __forceinline__ void score_epilogue(f32x4 (&acc)[TM][TN], const GemmParams& p, uint8_t* lds,
-                                               const float* bw_lds, bool bw_staged, int m_tile, int n_tile, int nbn) {
+                                               const float* bw_lds, int m_tile, int n_tile, int nbn) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
@@ -144,13 +149,18 @@ __device__ __forceinline__ void score_epilogue(f32x4 (&acc)[TM][TN], const GemmP
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wcol0 + tn * 16 + ccol;
-        if (bw_staged) {
-            bb[tn] = bw_lds[n];
-            ww[tn] = bw_lds[SCORE_BW_MAXN + n];
+        if constexpr (BW_STAGED) {
+            const uint32_t ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(bw_lds + n);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(bb[tn]) : "v"(ad));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ww[tn]) : "v"(ad), "n"(SCORE_BW_MAXN * 4));
         } else {
             bb[tn] = n < p.N ? p.b1[n] : 0.f;
             ww[tn] = n < p.N ? p.w2[n] : 0.f;
         }
+    }
+    if constexpr (BW_STAGED) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ReLU sign bits (all the backward needs of H) are packed per lane while the row dot is formed: element
     // e = (tm*4 + tn)*4 + j goes to bit 31 - e%32 of the lane's dword e/32 (v_alignbit shifts in the sign of -h)
@@ -198,7 +208,9 @@ __device__ __forceinline__ void score_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     // (the next write to `red` is a whole K loop of barriers away)
 }
 
-template <int EPI>
+// LIVE: the row tiles come from p.live_tiles (star_scorer_fwd_ragged); an instantiation of its own, so that the common
+// kernels carry neither its loads nor its registers (with it the staged EPI_SCORE kernel spilled two VGPRs).
+template <int EPI, bool BW_STAGED = true, bool LIVE = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
         const int xcd = vb & 7, local = vb >> 3;
         const int panel = (local / nbn) * 8 + xcd;
         nt = local % nbn;
-        if (PERSIST && p.live_tiles) {
+        if constexpr (PERSIST && LIVE) {
             sp = 0;
             if (panel >= p.n_live) return false;
             mt = p.live_tiles[panel];
@@ -380,9 +392,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     // EPI_SCORE: b1 / w2 of all columns into LDS once, so that the epilogues (which run while the next tile's DMA
     // is in flight) touch no register-destination global load -- hipcc would drain vmcnt(0) at its first use
     float* bw_lds = (float*)(lds + GEMM_LDS + 4096);
-    const bool bw_staged = PERSIST && (nbn * BN <= SCORE_BW_MAXN);
     if constexpr (PERSIST) {
-        if (bw_staged) {
+        if constexpr (BW_STAGED) {
             for (int n = tid; n < nbn * BN; n += GEMM_THREADS) {
                 bw_lds[n] = n < p.N ? p.b1[n] : 0.f;
                 bw_lds[SCORE_BW_MAXN + n] = n < p.N ? p.w2[n] : 0.f;
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             for (int tn = 0; tn < TN; ++tn) keep += (acc[tm][tn][0] + acc[tm][tn][1]) + (acc[tm][tn][2] + acc[tm][tn][3]);
         if (keep == 123.456f) p.partial[tid] = keep;
     } else if constexpr (EPI == EPI_SCORE) {
-        score_epilogue(acc, p, lds, bw_lds, bw_staged, m_tile, n_tile, nbn);
+        score_epilogue<BW_STAGED>(acc, p, lds, bw_lds, m_tile, n_tile, nbn);
     } else if constexpr (EPI == EPI_SLAB) {
         float* slab = p.slab + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -1015,7 +1026,8 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __r
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     int grid = (((p.live_tiles ? p.n_live : nbm * p.splits) + 7) / 8) * 8 * nbn;
-    static DevOnce once[4];
+    const bool bw_staged = nbn * BN <= SCORE_BW_MAXN;      // b1 / w2 fit behind the ring (d <= 3072)
+    static DevOnce once[4], live_once;
     static std::atomic<int> cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
@@ -1024,7 +1036,13 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     }
     bool ok = true;
     switch (epi) {
-        case EPI_SCORE: ok = reserve_lds_once(once[0], (const void*)gemm_nt_kernel<EPI_SCORE>, SCORE_LDS); break;
+        case EPI_SCORE:
+            if (p.live_tiles)
+                ok = reserve_lds_once(live_once, (const void*)gemm_nt_kernel<EPI_SCORE, false, true>, SCORE_LDS);
+            else
+                ok = bw_staged ? reserve_lds_once(once[0], (const void*)gemm_nt_kernel<EPI_SCORE, true>, SCORE_LDS)
+                               : reserve_lds_once(once[1], (const void*)gemm_nt_kernel<EPI_SCORE, false>, SCORE_LDS);
+            break;
         case EPI_SLAB: ok = reserve_lds_once(once[2], (const void*)gemm_nt_kernel<EPI_SLAB>, GEMM_LDS); break;
         default: ok = reserve_lds_once(once[3], (const void*)gemm_nt_kernel<EPI_ROWS>, EPI_LDS); break;
     }
@@ -1042,7 +1060,12 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
                 cus[dev & 63].store(n, std::memory_order_relaxed);
             }
             if (grid > n) grid = n;
-            hipLaunchKernelGGL(gemm_nt_kernel<EPI_SCORE>, dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
+            if (p.live_tiles)      // (b1 / w2 by global loads: this form is kept for the ABI, not for speed)
+                hipLaunchKernelGGL((gemm_nt_kernel<EPI_SCORE, false, true>), dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
+            else if (bw_staged)
+                hipLaunchKernelGGL((gemm_nt_kernel<EPI_SCORE, true>), dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
+            else
+                hipLaunchKernelGGL((gemm_nt_kernel<EPI_SCORE, false>), dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
             break;
         }
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
