@@ -1447,13 +1447,16 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
                 if (s.ilk_diag >= 0 && grp * 16 > q0 + 31 + s.ilk_diag) continue;      // nothing visible (uniform)
                 // S[q][key], dP[q][key] for two 16-query tiles (key on the lane, 4 queries per tile in registers):
                 // all sixteen A fragments are requested before the first MFMA
+                // dropout build: the swizzled fragment offsets are re-formed per slice (see the fused kernel)
+                int sw_tr_v = sw_tr, sw_row_v = sw_row;
+                if constexpr (DROP) asm volatile("" : "+v"(sw_tr_v), "+v"(sw_row_v));
                 bf16x8 qa[2][KS], ga[2][KS];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int rowoff = (q0 + 16 * t + r16) * ROWB;
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        const int off = rowoff + (((4 * ks + g) ^ sw_row) << 4);
+                        const int off = rowoff + (((4 * ks + g) ^ sw_row_v) << 4);
                         qa[t][ks] = lds_row8(q_lds + off);
                         ga[t][ks] = lds_row8(g_lds + off);
                     }
@@ -1482,7 +1485,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
                 bf16x8 gt[NT / 2], qt[NT / 2];
 #pragma unroll
                 for (int nt = 0; nt < NT / 2; ++nt) {
-                    const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                    const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr_v) << 4);
                     gt[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
                     qt[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
                 }
@@ -1514,7 +1517,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_dkv_small_kernel(
                     if (hlf == 0) {
 #pragma unroll
                         for (int nt = 0; nt < NT / 2; ++nt) {
-                            const int off = trbase + (((2 * (nt + NT / 2) + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                            const int off = trbase + (((2 * (nt + NT / 2) + ((lane & 3) >> 1)) ^ sw_tr_v) << 4);
                             gt2[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
                             qt2[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
                         }
@@ -1736,6 +1739,11 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
 #pragma unroll 1
         for (int sl = sl_first; sl < nslices; ++sl) {
             const int q0 = sl * 32;
+            // dropout build: the eight swizzled fragment offsets are re-formed in every slice instead of living in
+            // registers across the round (with the mask arithmetic they no longer fit: 14 spilled VGPRs, whose reloads
+            // wait vmcnt(0) and so drain the K / V prefetch)
+            int sw_tr_v = sw_tr, sw_row_v = sw_row;
+            if constexpr (DROP) asm volatile("" : "+v"(sw_tr_v), "+v"(sw_row_v));
             const int dsc0 = ((4 * sl + (g >> 1)) ^ sw_ds_row) << 4, dsc1 = ((4 * sl + 2 + (g >> 1)) ^ sw_ds_row) << 4;
             // no mask needed: every key of the group is valid and visible to every query of the slice
             const bool plain = (grp * 16 + 16 <= kend) && (q0 + 32 <= s.L) &&
@@ -1747,7 +1755,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
             bf16x8 kb[KS];
             if constexpr (HD == 128) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kb[ks] = lds_row8(krow_lds + (((4 * ks + g) ^ sw_row) << 4));
+                for (int ks = 0; ks < KS; ++ks) kb[ks] = lds_row8(krow_lds + (((4 * ks + g) ^ sw_row_v) << 4));
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kb[ks] = kfr[ks];
@@ -1764,7 +1772,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                 const int rowoff = (q0 + 16 * t + r16) * ROWB;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int off = rowoff + (((4 * ks + g) ^ sw_row) << 4);
+                    const int off = rowoff + (((4 * ks + g) ^ sw_row_v) << 4);
                     qa[ks] = lds_row8(q_lds + off);
                     ga[ks] = lds_row8(g_lds + off);
                 }
@@ -1779,7 +1787,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                 if (t == 1) {
 #pragma unroll
                     for (int nt = 0; nt < TPS; ++nt) {
-                        const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                        const int off = trbase + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr_v) << 4);
                         gt[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
                         qt[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
                     }
@@ -1835,7 +1843,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                 if (st < 3) {
 #pragma unroll
                     for (int nt = 0; nt < TPS; ++nt) {
-                        const int off = trbase + (((2 * (nt + (st + 1) * TPS) + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                        const int off = trbase + (((2 * (nt + (st + 1) * TPS) + ((lane & 3) >> 1)) ^ sw_tr_v) << 4);
                         gt2[nt] = lds_tr8(g_lds + off, g_lds + off + 16 * ROWB);
                         qt2[nt] = lds_tr8(q_lds + off, q_lds + off + 16 * ROWB);
                     }
@@ -1879,10 +1887,12 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                 if (k0 >= kend) break;                                                   // wave-uniform
                 if (s.ilk_diag >= 0 && k0 > qw0 + 15 + s.ilk_diag) break;                // invisible to all 16 queries
                 const int trb = (32 * kk + tr_row) * ROWB + 8 * (lane & 1);
+                int sw_tr_c = sw_tr;
+                if constexpr (DROP) asm volatile("" : "+v"(sw_tr_c));
                 bf16x8 kt[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int off = trb + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr) << 4);
+                    const int off = trb + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr_c) << 4);
                     kt[nt] = lds_tr8(k_lds + off, k_lds + off + 16 * ROWB);
                 }
                 const int dso = (32 * kk + tr_row) * DSB + 8 * (lane & 1) + (((2 * wid + ((lane & 3) >> 1)) ^ sw_ds_tr) << 4);
