@@ -473,6 +473,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
                     if (m < p.M && n < p.N) slab[(int64_t)m * p.N + n] = acc[tm][tn][j];
                 }
     } else {  // EPI_ROWS
+        // destination rows of this wave's eight 16-row blocks: all eight index loads are issued here, together (a load
+        // inside the store loop is waited for with vmcnt(0), which also waits for the stores of the block before it:
+        // eight serialised round trips, 41 -> see DESIGN.md)
+        int32_t orow_[8];
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int m = m0 + wrow0 + mb * 16 + (lane & 15);
+            orow_[mb] = p.out_rows[min(m, p.out_rows_n - 1)];
+        }
         uint8_t* W = lds + wid * EP_WAVE_BYTES;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             for (int mb = 0; mb < 8; ++mb) {
                 const int m = m0 + wrow0 + mb * 16 + (lane & 15);
                 const bool ok = m < p.out_rows_n;
-                const int64_t orow = ok ? p.out_rows[m] : 0;
+                const int64_t orow = orow_[mb];
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     const u32x4 v = ep_read_mrow(W, mb, nh, lane);     // every lane takes part in the LDS read
