@@ -908,22 +908,29 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
     // forward ran on a compacted frame list, the frame id itself otherwise
     const int32_t* brows = bit_rows ? bit_rows : rows;
     if (tid < GB_ROWS) {
-        const int r = r0 + tid;
-        const int m = r < R ? rows[r] : 0;
-        dsf[tid] = r < R ? ds[m] : 0.f;
-        bsh[tid] = relu_bit_pos(r < R ? brows[r] : 0, 0);
+        const int r = r0 + tid, rc = min(r, R - 1);
+        const float dv = ds[rows[rc]];
+        dsf[tid] = r < R ? dv : 0.f;
+        bsh[tid] = relu_bit_pos(brows[rc], 0);
     }
     {       // 128 B of bits per row: thread -> (row, 16-byte piece p of 8): wave column p / 4, lanes c = 4 (p % 4) .. +3
+        // both rows' loads first, without a branch around them (rows past R read row R-1's bits: their ds is 0): one
+        // memory round trip for the index loads and one for the bits, not two of each
         const int row = tid >> 3, p8 = tid & 7;
-        for (int rr = row; rr < GB_ROWS; rr += 32) {
-            const int r = r0 + rr;
-            u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-            if (r < R) v = *(const u32x4*)(bits + relu_bit_dword(brows[r], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
-            uint32_t* dstw = brow + rr * GB_PITCH + p8 * 4;
-            dstw[0] = v[0];
-            dstw[1] = v[1];
-            dstw[2] = v[2];
-            dstw[3] = v[3];
+        int64_t bm[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bm[j] = brows[min(r0 + row + 32 * j, R - 1)];
+        u32x4 v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            v[j] = *(const u32x4*)(bits + relu_bit_dword(bm[j], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t* dstw = brow + (row + 32 * j) * GB_PITCH + p8 * 4;
+            dstw[0] = v[j][0];
+            dstw[1] = v[j][1];
+            dstw[2] = v[j][2];
+            dstw[3] = v[j][3];
         }
     }
     __syncthreads();
