@@ -64,6 +64,22 @@ static_assert(EPI_LDS >= GEMM_LDS && EPI_LDS <= 160 * 1024, "epilogue staging mu
 
 enum { EPI_SCORE = 0, EPI_SLAB = 2, EPI_ROWS = 3 };
 
+// scorer backward reductions (scorer_bwd_finish_kernel), also runnable by extra workgroups of the dX GEMM launch
+struct FinishParams {
+    const float* slab;
+    int splits, d;
+    const __bf16* w1;
+    const float* b1;
+    const float* w2;
+    const float* colpart;
+    const float* dspart;
+    int nblk;
+    float* dw1;
+    float* dw2;
+    float* db1;
+    float* db2;
+};
+
 struct GemmParams {
     const __bf16* A;
     const __bf16* B;
@@ -86,6 +102,10 @@ struct GemmParams {
     int64_t ldo;
     const int32_t* out_rows;
     int out_rows_n;
+    // EPI_ROWS (optional): the last fin_blocks workgroups of the launch do the scorer backward's reductions instead of
+    // a GEMM tile (the dX GEMM at 12 k rows fills 188 of 256 CUs)
+    int fin_blocks;
+    FinishParams fin;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
@@ -208,11 +228,90 @@ __device__ __forceinline__ void score_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     // (the next write to `red` is a whole K loop of barriers away)
 }
 
+// ---- scorer backward reductions for one output row n of W1, by a group of 256 threads (tid 0..255):
+//   U[n][:] = sum of the split-K slabs;  c[n] = sum of the column partials;
+//   dW1[n][:] = w2[n] * U[n][:]     db1[n] = w2[n] * c[n]     dw2[n] = <W1[n][:], U[n][:]> + b1[n] * c[n]
+// (relu(h) = h * relu'(h), so sum_m ds[m] relu(h[m][n]) = <W1[n], U[n]> + b1[n] c[n]: no H needed);  db2 = sum ds.
+// Fixed summation orders: bitwise reproducible.  Part a leaves the group's wave partials in red / red2 (4 floats each);
+// the caller puts a workgroup barrier between part a and part b.
+__device__ __forceinline__ void finish_row_a(const FinishParams& f, int n, int tid, float* red, float* red2) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int d = f.d;
+    const int64_t dd = (int64_t)d * d;
+    const float wn = f.w2[n];
+    float dot = 0.f;
+    for (int k = tid * 4; k < d; k += 1024) {
+        const int64_t i = (int64_t)n * d + k;
+        // four slabs per round: their loads are independent and in flight together; the order stays fixed
+        f32x4 u = *(const f32x4*)(f.slab + i);
+        int sidx = 1;
+        for (; sidx + 3 < f.splits; sidx += 4) {
+            const f32x4 v0 = *(const f32x4*)(f.slab + (int64_t)(sidx + 0) * dd + i);
+            const f32x4 v1 = *(const f32x4*)(f.slab + (int64_t)(sidx + 1) * dd + i);
+            const f32x4 v2 = *(const f32x4*)(f.slab + (int64_t)(sidx + 2) * dd + i);
+            const f32x4 v3 = *(const f32x4*)(f.slab + (int64_t)(sidx + 3) * dd + i);
+            u += v0;
+            u += v1;
+            u += v2;
+            u += v3;
+        }
+        for (; sidx < f.splits; ++sidx) u += *(const f32x4*)(f.slab + (int64_t)sidx * dd + i);
+        const bf16x4 wv = *(const bf16x4*)(f.w1 + i);
+        dot += ((float)wv[0] * u[0] + (float)wv[1] * u[1]) + ((float)wv[2] * u[2] + (float)wv[3] * u[3]);
+        *(f32x4*)(f.dw1 + i) = u * wn;
+    }
+    float c = 0.f;
+    for (int t = tid; t < f.nblk; t += 256) c += f.colpart[(int64_t)t * d + n];
+    dot = wave_sum(dot);
+    c = wave_sum(c);
+    if (lane == 0) {
+        red[wid] = dot;
+        red2[wid] = c;
+    }
+}
+__device__ __forceinline__ void finish_row_b(const FinishParams& f, int n, int tid, const float* red, const float* red2) {
+    const int lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) {
+        const float dsum = (red[0] + red[1]) + (red[2] + red[3]);
+        const float csum = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+        f.dw2[n] = dsum + f.b1[n] * csum;
+        f.db1[n] = f.w2[n] * csum;
+    }
+    if (n == 0 && wid == 1) {                      // db2: one wave, lane-strided partial sums, then a fixed tree
+        float s2 = 0.f;
+        for (int t = lane; t < f.nblk; t += 64) s2 += f.dspart[t];
+        s2 = wave_sum(s2);
+        if (lane == 0) f.db2[0] = s2;
+    }
+}
+// the same for a 512-thread workgroup `blk` of `nblocks`: its two halves take rows 2 i, 2 i + 1 of its share
+__device__ __forceinline__ void finish_rows_block(const FinishParams& f, int blk, int nblocks, float* scratch) {
+    const int tid = threadIdx.x, half = tid >> 8, t256 = tid & 255;
+    float* red = scratch + half * 8;
+    float* red2 = red + 4;
+    const int per = ((f.d + nblocks - 1) / nblocks + 1) & ~1;              // rows per workgroup, even
+    for (int i = 0; i < per; i += 2) {
+        const int n = blk * per + i + half;
+        const bool ok = n < f.d && i + half < per;
+        if (ok) finish_row_a(f, n, t256, red, red2);
+        __syncthreads();
+        if (ok) finish_row_b(f, n, t256, red, red2);
+        __syncthreads();
+    }
+}
+
 // LIVE: the row tiles come from p.live_tiles (star_scorer_fwd_ragged); an instantiation of its own, so that the common
 // kernels carry neither its loads nor its registers (with it the staged EPI_SCORE kernel spilled two VGPRs).
 template <int EPI, bool BW_STAGED = true, bool LIVE = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if constexpr (EPI == EPI_ROWS) {
+        const int first_fin = (int)gridDim.x - p.fin_blocks;
+        if ((int)blockIdx.x >= first_fin) {        // (fin_blocks = 0: never)
+            finish_rows_block(p.fin, (int)blockIdx.x - first_fin, p.fin_blocks, (float*)lds);
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform
     const int wr = wid >> 2, wc = wid & 3;
@@ -980,63 +1079,12 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
     }
 }
 
-// One workgroup per output row n of W1:  U[n][:] = sum of the split-K slabs;  c[n] = sum of the column partials;
-//   dW1[n][:] = w2[n] * U[n][:]     db1[n] = w2[n] * c[n]     dw2[n] = <W1[n][:], U[n][:]> + b1[n] * c[n]
-// (relu(h) = h * relu'(h), so sum_m ds[m] relu(h[m][n]) = <W1[n], U[n]> + b1[n] c[n]: no H needed);  db2 = sum ds.
-// Fixed summation orders: bitwise reproducible.
-__global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(const float* __restrict__ slab, int splits, int d,
-                                                                const __bf16* __restrict__ w1, const float* __restrict__ b1,
-                                                                const float* __restrict__ w2,
-                                                                const float* __restrict__ colpart,
-                                                                const float* __restrict__ dspart, int nblk,
-                                                                float* __restrict__ dw1, float* __restrict__ dw2,
-                                                                float* __restrict__ db1, float* __restrict__ db2) {
+// One workgroup per output row n of W1 (finish_row_a / _b above).
+__global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(FinishParams f) {
     __shared__ float red[4], red2[4];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t dd = (int64_t)d * d;
-    const float wn = w2[n];
-    float dot = 0.f;
-    for (int k = tid * 4; k < d; k += 1024) {
-        const int64_t i = (int64_t)n * d + k;
-        // four slabs per round: their loads are independent and in flight together; the order stays fixed
-        f32x4 u = *(const f32x4*)(slab + i);
-        int sidx = 1;
-        for (; sidx + 3 < splits; sidx += 4) {
-            const f32x4 v0 = *(const f32x4*)(slab + (int64_t)(sidx + 0) * dd + i);
-            const f32x4 v1 = *(const f32x4*)(slab + (int64_t)(sidx + 1) * dd + i);
-            const f32x4 v2 = *(const f32x4*)(slab + (int64_t)(sidx + 2) * dd + i);
-            const f32x4 v3 = *(const f32x4*)(slab + (int64_t)(sidx + 3) * dd + i);
-            u += v0;
-            u += v1;
-            u += v2;
-            u += v3;
-        }
-        for (; sidx < splits; ++sidx) u += *(const f32x4*)(slab + (int64_t)sidx * dd + i);
-        const bf16x4 wv = *(const bf16x4*)(w1 + i);
-        dot += ((float)wv[0] * u[0] + (float)wv[1] * u[1]) + ((float)wv[2] * u[2] + (float)wv[3] * u[3]);
-        *(f32x4*)(dw1 + i) = u * wn;
-    }
-    float c = 0.f;
-    for (int t = tid; t < nblk; t += 256) c += colpart[(int64_t)t * d + n];
-    dot = wave_sum(dot);
-    c = wave_sum(c);
-    if (lane == 0) {
-        red[wid] = dot;
-        red2[wid] = c;
-    }
+    finish_row_a(f, blockIdx.x, threadIdx.x, red, red2);
     __syncthreads();
-    if (tid == 0) {
-        const float dsum = (red[0] + red[1]) + (red[2] + red[3]);
-        const float csum = (red2[0] + red2[1]) + (red2[2] + red2[3]);
-        dw2[n] = dsum + b1[n] * csum;
-        db1[n] = wn * csum;
-    }
-    if (n == 0 && wid == 1) {                      // db2: one wave, lane-strided partial sums, then a fixed tree
-        float s2 = 0.f;
-        for (int t = lane; t < nblk; t += 64) s2 += dspart[t];
-        s2 = wave_sum(s2);
-        if (lane == 0) db2[0] = s2;
-    }
+    finish_row_b(f, blockIdx.x, threadIdx.x, red, red2);
 }
 
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
@@ -1085,7 +1133,9 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
             break;
         }
         case EPI_SLAB: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SLAB>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS, st, p); break;
-        default: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid), dim3(GEMM_THREADS), EPI_LDS, st, p); break;
+        default:
+            hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWS>, dim3(grid + p.fin_blocks), dim3(GEMM_THREADS), EPI_LDS, st, p);
+            break;
     }
     return STAR_OK;
 }
@@ -1375,6 +1425,7 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
                            (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
     if (aux != st && !tn) STAR_HIP(hipEventRecord(ev_join[0], aux));
     if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
+    if (aux != st && tn) STAR_HIP(hipEventRecord(ev_join[0], aux));       // TN form: join0 = the zero-fill is done
     // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials
     static_assert(GB_COLS == 128, "d is a multiple of 128");
     hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk, d / GB_COLS), dim3(256), 0, st, (const uint32_t*)relu_bits,
@@ -1402,14 +1453,23 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         q.ldb = Rpad;
         if (int rc = launch_gemm(EPI_SLAB, q, st)) return rc;
     }
-    // 3. dX rows = G' . (diag(w2) W1) on aux (behind the zero-fill of dx), beside
-    // 4. the reductions on the main stream: dW1 = diag(w2) U, dw2, db1, db2
-    if (aux != st) {
-        STAR_HIP(hipEventRecord(ev_fork[1], st));
-        STAR_HIP(hipStreamWaitEvent(aux, ev_fork[1], 0));
-    }
+    // 3. + 4. dX rows = G' . (diag(w2) W1) and the reductions dW1 = diag(w2) U, dw2, db1, db2.
+    FinishParams fin = {};
+    fin.slab = slab;
+    fin.splits = L.splits;
+    fin.d = d;
+    fin.w1 = (const __bf16*)w1;
+    fin.b1 = b1;
+    fin.w2 = w2;
+    fin.colpart = colpart;
+    fin.dspart = dspart;
+    fin.nblk = L.nblk;
+    fin.dw1 = dw1;
+    fin.dw2 = dw2;
+    fin.db1 = db1;
+    fin.db2 = db2;
+    GemmParams r = {};
     if (dx) {
-        GemmParams r = {};
         r.A = G;
         r.B = (const __bf16*)w1ts;
         r.lda = d;
@@ -1422,13 +1482,27 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         r.ldo = d;
         r.out_rows = rows;
         r.out_rows_n = (int)R;
-        if (int rc = launch_gemm(EPI_ROWS, r, aux)) return rc;
     }
-    if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
-    hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(d), dim3(256), 0, st, (const float*)slab, L.splits, d,
-                       (const __bf16*)w1, b1, w2, (const float*)colpart, (const float*)dspart, L.nblk, dw1, dw2, db1,
-                       db2);
-    if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[1], 0));
+    if (dx && tn) {
+        // TN form: ONE launch on the main stream -- the GEMM tiles plus 64 workgroups that do the reductions (at 12 k rows
+        // the GEMM fills 188 CUs; a second stream for the reductions cost a 10-us cross-queue hand-over in the graph).
+        // Only the zero-fill of dx ran on aux.
+        if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));
+        r.fin_blocks = 64;
+        r.fin = fin;
+        if (int rc = launch_gemm(EPI_ROWS, r, st)) return rc;
+    } else {
+        // NT form: dX GEMM on aux (behind the zero-fill of dx), the reductions on the main stream
+        if (aux != st) {
+            STAR_HIP(hipEventRecord(ev_fork[1], st));
+            STAR_HIP(hipStreamWaitEvent(aux, ev_fork[1], 0));
+        }
+        if (dx)
+            if (int rc = launch_gemm(EPI_ROWS, r, aux)) return rc;
+        if (aux != st) STAR_HIP(hipEventRecord(ev_join[1], aux));
+        hipLaunchKernelGGL(scorer_bwd_finish_kernel, dim3(d), dim3(256), 0, st, fin);
+        if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[1], 0));
+    }
 #undef STAR_HIP
     STAR_LAUNCH_CHECK("star_scorer_bwd");
     return STAR_OK;
