@@ -997,11 +997,21 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
                                                            const int32_t* __restrict__ bit_rows, int R, int Rpad, int d,
                                                            __bf16* __restrict__ G,
                                                            __bf16* __restrict__ GT, float* __restrict__ colpart,
-                                                           float* __restrict__ dspart) {
+                                                           float* __restrict__ dspart, int nblk,
+                                                           u32x4* __restrict__ zfill, int64_t zfill_n16) {
     __shared__ uint32_t brow[GB_ROWS * GB_PITCH];
     __shared__ float dsf[GB_ROWS];
     __shared__ int bsh[GB_ROWS];                   // bit position of (row, tn = 0); tn lowers it by 4
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nblk) {
+        // the workgroups past the row blocks zero-fill dx (store-only waves beside the issue-bound G' blocks: the fill
+        // costs HBM write time this launch has to spare, and no second stream)
+        const int64_t nz = (int64_t)(gridDim.x - nblk) * gridDim.y * 256;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int64_t i = ((int64_t)(blockIdx.x - nblk) * gridDim.y + blockIdx.y) * 256 + tid; i < zfill_n16; i += nz)
+            zfill[i] = z;
+        return;
+    }
     const int r0 = blockIdx.x * GB_ROWS, n0 = blockIdx.y * GB_COLS;
     // rows[r] = frame id (indexes ds); the forward's GEMM row of that frame (indexes the bits) is bit_rows[r] when the
     // forward ran on a compacted frame list, the frame id itself otherwise
@@ -1414,22 +1424,32 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
             return STAR_ERR_LAUNCH;                                                                 \
         }                                                                                           \
     } while (0)
+    // TN form: everything on `stream` (the aux stream and its events go unused)
+    if (tn) aux = st;
     if (aux != st) {
         STAR_HIP(hipEventRecord(ev_fork[0], st));
         STAR_HIP(hipStreamWaitEvent(aux, ev_fork[0], 0));
     }
     // aux: X_sel^T for the NT form first (the dW1 GEMM waits for it), then the zero-fill of dx (rows that are not
     // listed), which only the dX GEMM -- issued on aux behind it -- needs
-    if (!tn)
+    if (!tn) {
         hipLaunchKernelGGL(gather_transpose_kernel, dim3((unsigned)(Rpad / 64), d / 64), dim3(256), 0, aux,
                            (const __bf16*)x, (int64_t)d, rows, (int)R, (int)Rpad, d, XT);
-    if (aux != st && !tn) STAR_HIP(hipEventRecord(ev_join[0], aux));
-    if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
-    if (aux != st && tn) STAR_HIP(hipEventRecord(ev_join[0], aux));       // TN form: join0 = the zero-fill is done
-    // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials
+        if (aux != st) STAR_HIP(hipEventRecord(ev_join[0], aux));
+        if (dx && !dx_zeroed) STAR_HIP(hipMemsetAsync(dx, 0, (size_t)N * d * 2, aux));
+    }
+    // 1. G' = ds * relu'(H) from the forward's sign bits: G' (for dX), G'^T (for dW1), column partials.  TN form: the
+    // launch also carries the zero-fill of dx (about 1024 extra workgroups)
     static_assert(GB_COLS == 128, "d is a multiple of 128");
-    hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk, d / GB_COLS), dim3(256), 0, st, (const uint32_t*)relu_bits,
-                       (d + BN - 1) / BN, dscores, rows, bit_rows, (int)R, (int)Rpad, d, G, GT, colpart, dspart);
+    const bool zfill = tn && dx && !dx_zeroed;
+    if (zfill && ((uintptr_t)dx & 15)) {
+        set_error("star_scorer_bwd: dx must be 16-byte aligned");
+        return STAR_ERR_ARG;
+    }
+    const int zx = zfill ? (int)cdiv((int64_t)1024, (int64_t)(d / GB_COLS)) : 0;
+    hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk + zx, d / GB_COLS), dim3(256), 0, st,
+                       (const uint32_t*)relu_bits, (d + BN - 1) / BN, dscores, rows, bit_rows, (int)R, (int)Rpad, d, G, GT,
+                       colpart, dspart, L.nblk, zfill ? (u32x4*)dx : nullptr, zfill ? N * d / 8 : (int64_t)0);
     if (aux != st && !tn) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));     // X_sel^T is ready
     // 2. U = G'^T . X_sel  (split-K slabs)
     GemmParams q = {};
@@ -1486,8 +1506,7 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
     if (dx && tn) {
         // TN form: ONE launch on the main stream -- the GEMM tiles plus 64 workgroups that do the reductions (at 12 k rows
         // the GEMM fills 188 CUs; a second stream for the reductions cost a 10-us cross-queue hand-over in the graph).
-        // Only the zero-fill of dx ran on aux.
-        if (aux != st) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));
+        // The zero-fill of dx rode in the G' launch.
         r.fin_blocks = 64;
         r.fin = fin;
         if (int rc = launch_gemm(EPI_ROWS, r, st)) return rc;
