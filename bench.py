@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--staged", action="store_true",
+                    help="diagnostic: run the N > 1 step structure (one graph per decoder layer's attention backward) at "
+                         "N = 1, to price its replay gaps; the line is marked as a custom configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-all", action="store_true", help="skip the per-kernel-class roofline legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -185,7 +188,8 @@ def main():
 
     from star_amd import _lib, ops
     from star_amd.nugget import NuggetScorer
-    from star_amd.step import attention_backward, backward_rest, make_inputs, nugget_step_asr, nugget_step_simul
+    from star_amd.step import (attention_backward, attention_backward_layer, backward_rest, backward_rest_layers,
+                               make_inputs, nugget_step_asr, nugget_step_simul)
 
     wl = workload(args, rank)
     B, T, L, d, h, nl, rate = wl["B"], wl["T"], wl["L"], args.dim, args.heads, args.layers, args.rate
@@ -209,7 +213,9 @@ def main():
         # decoder cross-attention parameter gradients per layer: c_attn d x 2d, q_attn d x d, c_proj d x d, their
         # biases (4d) and ln_cross_attn (2d).  The weights are outside the hot path; their
         # all-reduce is part of the step, so the buffer has the real size.
-        decoder_side = sd.SideStreamAllReduce(torch.zeros(nl * (4 * d * d + 6 * d), dtype=torch.float32, device=dev))
+        # One bucket per decoder layer, started as soon as that layer's attention backward is queued (DDP's bucketed
+        # overlap): the collective runs beside the remaining layers' backward and the gather / scorer backward.
+        decoder_side = sd.BucketedSideAllReduce(torch.zeros(nl * (4 * d * d + 6 * d), dtype=torch.float32, device=dev), nl)
 
     def reset_grads():
         for t in grad_targets:
@@ -222,58 +228,81 @@ def main():
             return nugget_step_simul(scorer, inp, use_ilk=wl["ilk"], backward=False)
         return nugget_step_asr(scorer, inp, rate, backward=False)
 
-    def rest(out, dmem, dsg):
+    staged = world > 1 or args.staged
+
+    def extra(out):
         if simul:
             ql = out["quantity_loss"]
-            backward_rest(out, dmem, dsg, [ql], [torch.full_like(ql, 0.01)])
-        else:
-            backward_rest(out, dmem, dsg)
+            return [ql], [torch.full_like(ql, 0.01)]
+        return None, None
 
-    def step():                                  # eager
+    def step():                                  # eager, N = 1 structure
         reset_grads()
         out = forward()
         dmem, dsg = attention_backward(out, inp)
-        rest(out, dmem, dsg)
+        backward_rest(out, dmem, dsg, *extra(out))
+
+    def step_layers(comm):                       # eager, N > 1 structure: layer by layer, last layer first
+        reset_grads()
+        out = forward()
+        lg = [None] * nl
+        for l in reversed(range(nl)):
+            lg[l] = attention_backward_layer(out, inp, l)
+            if comm and world > 1:
+                decoder_side.start(l, world)
+        backward_rest_layers(out, lg, *extra(out))
 
     # ---- eager warm-up (also fills the per-rate caches and the allocator), then graph capture
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):
-            step()
+            if staged:
+                step_layers(False)
+            else:
+                step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph_a = graph_b = None
+    graph_a = None
+    graphs_l, graph_r = [], None
     if not args.no_graph:
-        # N > 1: two graphs, forward + attention backward | gather / scorer backward, with the start of the decoder-side
-        # all-reduce between them; N = 1: one graph.
+        # N = 1: one graph.  N > 1: forward | attention backward of layer nl-1 | ... | layer 0 | gather / scorer backward,
+        # with the start of a decoder-side all-reduce bucket after every layer graph (RCCL launches stay outside the
+        # graphs).
         reset_grads()
         graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_a):
             if world > 1:
                 allreduce.zero()               # part of the replayed step: backward accumulates into the buffer
             out_c = forward()
-            dmem_c, dsg_c = attention_backward(out_c, inp)
-            if world == 1:                     # nothing happens between the halves: one graph, no replay gap
-                rest(out_c, dmem_c, dsg_c)
-        if world > 1:
-            graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_b, pool=graph_a.pool()):
-                rest(out_c, dmem_c, dsg_c)
+            if not staged:                     # nothing happens between the halves: one graph, no replay gap
+                dmem_c, dsg_c = attention_backward(out_c, inp)
+                backward_rest(out_c, dmem_c, dsg_c, *extra(out_c))
+        if staged:
+            lg_c = [None] * nl
+            for l in reversed(range(nl)):
+                g_l = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_l, pool=graph_a.pool()):
+                    lg_c[l] = attention_backward_layer(out_c, inp, l)
+                graphs_l.append((l, g_l))
+            graph_r = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_r, pool=graph_a.pool()):
+                backward_rest_layers(out_c, lg_c, *extra(out_c))
 
     def run_step(with_allreduce=True):
-        if graph_a is not None:
-            graph_a.replay()
+        if graph_a is None:
+            if staged:
+                step_layers(with_allreduce)
+            else:
+                step()
         else:
-            reset_grads()
-            out = forward()
-            dmem, dsg = attention_backward(out, inp)
-        if world > 1 and with_allreduce:
-            decoder_side.start(world)            # side stream: runs beside the gather / scorer backward
-        if graph_b is not None:
-            graph_b.replay()
-        elif graph_a is None:
-            rest(out, dmem, dsg)
+            graph_a.replay()
+            for l, g_l in graphs_l:
+                g_l.replay()
+                if with_allreduce and world > 1:
+                    decoder_side.start(l, world)   # side stream: runs beside everything queued after this point
+            if graph_r is not None:
+                graph_r.replay()
         if world > 1 and with_allreduce:
             allreduce(world)
             decoder_side.join()
@@ -370,7 +399,7 @@ def main():
 
     if rank == 0:
         headline = args.config != 1 or (B, T, d, h, L, nl) == (32, 1500, 1024, 8, 128, 4)
-        headline = headline and args.batch is None and args.frames is None and args.tgt is None
+        headline = headline and args.batch is None and args.frames is None and args.tgt is None and not args.staged
         n_dec = decoder_side.flat.numel() if decoder_side is not None else 0
         rec = {
             "metric": "encoder frames/sec, nugget scorer+select+cross-attn fwd+bwd",
@@ -396,8 +425,9 @@ def main():
                        "loss_scalar": "not formed in the timed step: the cotangents G_l of loss = sum_l <O_l, G_l> are fed "
                                       "to backward directly (one reduction kernel per layer left out; tests form the scalar)",
                        "grad_allreduce": ("2 flat fp32 buffers per step: scorer (%d values) after the step; decoder "
-                                          "cross-attention parameters (%d values) on a side stream after the attention "
-                                          "backward" % (allreduce.flat.numel(), n_dec)) if world > 1 else None,
+                                          "cross-attention parameters (%d values) in one bucket per layer on a side "
+                                          "stream, each started behind its layer's attention backward"
+                                          % (allreduce.flat.numel(), n_dec)) if world > 1 else None,
                        "allreduce_bytes": 4 * (allreduce.flat.numel() + n_dec) if world > 1 else None,
                        "compute_only_ms_per_step": compute_ms,
                        "with_allreduce_ms_per_step": ms_per_step if world > 1 else None,

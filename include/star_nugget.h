@@ -305,10 +305,11 @@ int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const
  * dW1 GEMM: a TN kernel reads G' and the listed rows of x in place; beyond 114688 rows (d <= 1024: 16 K splits) an NT
  *   kernel runs on transposed copies (G'^T from the G' pass, X_sel^T from a gather-transpose pass) -- same results up
  *   to fp32 rounding.
- * aux_stream (may be NULL): a second stream of the same device.  When given, the zero-fill of dx runs on it beside the
- *   G' pass and the dW1 GEMM (NT form: also X_sel^T and the dX GEMM, beside the reductions); the call forks from
- *   and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
- *   `stream` captures both branches).
+ * aux_stream (may be NULL): a second stream of the same device.  The TN form does not use it (everything runs on
+ *   `stream`: the zero-fill of dx rides in the G' launch, the reductions in the dX GEMM's).  NT form, when given: X_sel^T,
+ *   the zero-fill of dx and the dX GEMM run on it beside the G' pass, the dW1 GEMM and the reductions; the call forks
+ *   from and joins back into `stream`, so the caller still orders everything on `stream` alone (HIP-graph capture of
+ *   `stream` captures both branches).  dx must be 16-byte aligned.
  * aux_events_host: HOST array of four hipEvent_t created by the caller (hipEventDisableTiming suffices), required
  *   when aux_stream is given: the fork / join events of this call.  One set per (stream, aux_stream) pair: calls that
  *   may overlap in time (other threads, other stream pairs) bring their own sets, so the library holds no event.

@@ -91,7 +91,7 @@ def _attend(inp: StepInputs, mem, bias, key_len, ilk_diag, with_loss: bool):
     if with_loss:
         with torch.no_grad():
             loss = sum((o.float() * g.float()).sum() for o, g in zip(outs, inp.gs))
-    return outs, loss
+    return outs, loss, kvs, biases
 
 
 def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward: bool = True,
@@ -105,11 +105,11 @@ def nugget_step_asr(scorer: NuggetScorer, inp: StepInputs, rate: float, backward
     nmask, idx, sg, table, pos, rows = ops.topk_select(scores, lengths=inp.lengths_dev, rate=rate, K=K, want_rows=True)
     scorer.set_active_rows(rows)
     mem = ops.gather_rows(inp.s, idx)
-    outs, loss = _attend(inp, mem, sg, key_len, -1, with_loss)
+    outs, loss, kvs, biases = _attend(inp, mem, sg, key_len, -1, with_loss)
     if backward:
         torch.autograd.backward(outs, inp.gs)
     return {"scores": scores, "nugget_mask": nmask, "indices": idx, "scores_gather": sg, "type_table": table,
-            "positions": pos, "mem": mem, "loss": loss, "outs": outs}
+            "positions": pos, "mem": mem, "loss": loss, "outs": outs, "kvs": kvs, "biases": biases}
 
 
 def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, backward: bool = True,
@@ -127,13 +127,14 @@ def nugget_step_simul(scorer: NuggetScorer, inp: StepInputs, use_ilk: bool, back
     alphas, qloss, resized, idx, nmask, counts, mx, nugget_scores, table, pos = ops.cif_segment(
         scores, inp.target_lengths_dev, inp.lengths_dev, cap=cap)
     mem = ops.gather_rows(inp.s, idx)                                                    # :446-447
-    outs, loss = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1, with_loss)
+    outs, loss, kvs, biases = _attend(inp, mem, nugget_scores, counts, 2 if use_ilk else -1, with_loss)
     total = None if loss is None else loss + 0.01 * qloss.detach()                       # :461
     if backward:
         torch.autograd.backward(outs + [qloss], inp.gs + [torch.full_like(qloss, 0.01)])
     return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
             "nugget_mask": nmask, "counts": counts, "max_count": mx, "scores_gather": nugget_scores,
-            "type_table": table, "positions": pos, "mem": mem, "loss": total, "outs": outs}
+            "type_table": table, "positions": pos, "mem": mem, "loss": total, "outs": outs, "kvs": kvs,
+            "biases": biases}
 
 
 def attention_backward(out, inp: StepInputs):
@@ -142,6 +143,30 @@ def attention_backward(out, inp: StepInputs):
     this stage, so their all-reduce can start while backward_rest() runs."""
     grads = torch.autograd.grad(out["outs"], [out["mem"], out["scores_gather"]] + list(inp.qs), inp.gs)
     return grads[0], grads[1]
+
+
+def attention_backward_layer(out, inp: StepInputs, l: int):
+    """The attention backward of decoder layer l alone (multi-GPU step with one all-reduce bucket per layer, as DDP
+    overlaps its buckets with the backward): returns (dK_l, dV_l, d bias_l partials), the cotangents of the layer's
+    inputs this side of the shared nodes (K/V fan-out, shared bias), which backward_rest_layers() runs once."""
+    k, v, b = out["kvs"][2 * l], out["kvs"][2 * l + 1], out["biases"][l]
+    g = torch.autograd.grad([out["outs"][l]], [k, v, b, inp.qs[l]], [inp.gs[l]])
+    return g[0], g[1], g[2]
+
+
+def backward_rest_layers(out, layer_grads, extra=None, extra_grads=None):
+    """After attention_backward_layer() for every layer (any order): fan-out backward, the bias-gradient reduction of all
+    layers, row-gather backward, score scatter and the scorer backward.  layer_grads[l] = that layer's triple."""
+    nl = len(out["outs"])
+    roots, gr = [], []
+    for l in range(nl):
+        roots += [out["kvs"][2 * l], out["kvs"][2 * l + 1]]
+        gr += [layer_grads[l][0], layer_grads[l][1]]
+    roots += [out["biases"][l] for l in range(nl)]
+    gr += [layer_grads[l][2] for l in range(nl)]
+    if extra is not None:
+        roots, gr = roots + list(extra), gr + list(extra_grads)
+    torch.autograd.backward(roots, gr)
 
 
 def backward_rest(out, dmem, dsg, extra=None, extra_grads=None):

@@ -130,6 +130,73 @@ def test_two_buffer_two_stage_backward_matches_single_process(tmp_path):
     np.testing.assert_allclose(got["dec"].numpy(), (fdec.grad / 2).numpy(), rtol=1e-5, atol=1e-6)
 
 
+def _layered_loss(x, lengths, rate, params, decs):
+    """Stand-in with nl decoder layers fed from one boundary: returns (per-layer losses, per-layer boundary copies, sg)."""
+    from oracle import nugget_oracle as orc
+    w1, b1, w2, b2 = params
+    t = x.shape[1]
+    mask = np.arange(t)[None, :] < np.asarray(lengths)[:, None]
+    s = orc.scorer(x, w1, b1, w2, b2)
+    nmask, idx, _ = orc.topk_select(s.detach().numpy(), mask, rate)
+    sg = s.gather(1, torch.from_numpy(idx)) * torch.from_numpy(nmask)
+    feeds = [sg * 1.0 for _ in decs]             # the per-layer inputs this side of the shared node (like K_l / V_l)
+    losses = [(torch.tanh(f.unsqueeze(-1) * dd.unsqueeze(0).unsqueeze(0)) ** 2).sum() for f, dd in zip(feeds, decs)]
+    return losses, feeds, sg
+
+
+def _worker3(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from star_amd import dist as sd
+    sd.init(backend="gloo")
+    data = torch.load(os.path.join(tmp, "data.pt"))
+    mine = sd.shard(list(range(len(data["lengths"]))), rank, world)
+    params = [torch.nn.Parameter(p.clone()) for p in data["params"]]
+    decs = [torch.nn.Parameter(dd.clone()) for dd in data["decs"]]
+    nl, m = len(decs), decs[0].numel()
+    ar = sd.FlatGradAllReduce(params).attach()
+    ar.zero()
+    side = sd.BucketedSideAllReduce(torch.zeros(nl * m), nl)
+    losses, feeds, sg = _layered_loss(data["x"][mine], [data["lengths"][i] for i in mine], 4, params, decs)
+    # bench.py's N > 1 step: layer by layer (last first), a bucket started behind every layer, then the rest
+    dfeeds = [None] * nl
+    for l in reversed(range(nl)):
+        dfeeds[l], ddec = torch.autograd.grad(losses[l], [feeds[l], decs[l]])
+        side.buckets[l].copy_(ddec.reshape(-1))
+        side.start(l, world)
+    torch.autograd.backward(feeds, dfeeds)
+    ar(world)
+    side.join()
+    sd.barrier()
+    if rank == 0:
+        torch.save({"params": [p.grad for p in params], "dec": side.flat}, os.path.join(tmp, "grads.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_bucket_per_layer_backward_matches_single_process(tmp_path):
+    torch.manual_seed(2)
+    d, t, b, m, nl = 16, 40, 5, 6, 3
+    lengths = [40, 12, 29, 40, 9]
+    x = torch.randn(b, t, d)
+    params = [torch.randn(d, d) * 0.2, torch.randn(d) * 0.1, torch.randn(1, d) * 0.2, torch.randn(1) * 0.1]
+    decs = [torch.randn(m) * 0.5 for _ in range(nl)]
+    torch.save({"x": x, "lengths": lengths, "params": params, "decs": decs}, tmp_path / "data.pt")
+    port = 30711 + os.getpid() % 200
+    mp.spawn(_worker3, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "grads.pt")
+    full = [torch.nn.Parameter(p.clone()) for p in params]
+    fdecs = [torch.nn.Parameter(dd.clone()) for dd in decs]
+    sum(_layered_loss(x, lengths, 4, full, fdecs)[0]).backward()
+    for g, p in zip(got["params"], full):
+        np.testing.assert_allclose(g.numpy(), (p.grad / 2).numpy(), rtol=1e-5, atol=1e-6)
+    ref = torch.cat([dd.grad.reshape(-1) for dd in fdecs]) / 2
+    np.testing.assert_allclose(got["dec"].numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        from star_amd import dist as sd
+        sd.BucketedSideAllReduce(torch.zeros(7), 2)
+
+
 def test_shard_partitions_everything():
     from star_amd import dist as sd
     items = list(range(13))

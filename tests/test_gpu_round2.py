@@ -418,9 +418,10 @@ def test_two_stage_backward_equals_single_backward(ops):
     """bench.py's multi-GPU step splits the backward after the attention kernels (star_amd.step.attention_backward /
     backward_rest).  Same kernels in the same order on the same operands: bit-identical gradients."""
     from star_amd.nugget import NuggetScorer
-    from star_amd.step import attention_backward, backward_rest, make_inputs, nugget_step_asr, nugget_step_simul
+    from star_amd.step import (attention_backward, attention_backward_layer, backward_rest, backward_rest_layers,
+                               make_inputs, nugget_step_asr, nugget_step_simul)
     torch.manual_seed(2)
-    lengths, T, d, h, nl = [200, 180, 77], 200, 256, 4, 2
+    lengths, T, d, h, nl = [200, 180, 77], 200, 256, 4, 3
     tl = [int(round(0.075 * n)) + 2 for n in lengths]
     scorer = NuggetScorer(d).to(DEV)
     inp = make_inputs(lengths, T, d, h, max(tl), nl, DEV, target_lengths=tl)
@@ -447,14 +448,27 @@ def test_two_stage_backward_equals_single_backward(ops):
         else:
             backward_rest(out, dmem, dsg)
         two = grads()
+        # N > 1 structure: one stage per decoder layer (last layer first), then the shared nodes and the rest
+        out = nugget_step_simul(scorer, inp, use_ilk=True, backward=False) if simul else \
+            nugget_step_asr(scorer, inp, 4, backward=False)
+        lg = [None] * nl
+        for l in reversed(range(nl)):
+            lg[l] = attention_backward_layer(out, inp, l)
+        if simul:
+            ql = out["quantity_loss"]
+            backward_rest_layers(out, lg, [ql], [torch.full_like(ql, 0.01)])
+        else:
+            backward_rest_layers(out, lg)
+        three = grads()
         nq = len(leaves) - len(inp.qs)
-        for i, (a, b) in enumerate(zip(one, two)):
-            if i >= nq:
-                assert b is None                        # autograd.grad returns dQ instead of accumulating it
-                continue
-            assert (a is None) == (b is None)
-            if a is not None:
-                assert torch.equal(a, b)
+        for other in (two, three):
+            for i, (a, b) in enumerate(zip(one, other)):
+                if i >= nq:
+                    assert b is None                        # autograd.grad returns dQ instead of accumulating it
+                    continue
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)
 
 
 def _simul_full_size(ops, B, T, lengths, tl, use_ilk, seed):
