@@ -48,7 +48,7 @@ struct alignas(sizeof(T) * N) Pack {
 
 // T_ELEM: __bf16 or float; rows are d elements, moved VEC elements per lane per step
 // (VEC = 4 when d % 4 == 0, else 1 -- the scalar score gather of w2v_simul.py:427 has d = 1).
-constexpr int GB_MAXV = 4;     // row vectors per lane kept in registers by the duplicate path (d <= 1024 at VEC 4)
+constexpr int GB_DUP = 16;     // source rows of a duplicated frame that a wave keeps in flight
 
 template <typename T_ELEM, int VEC>
 __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __restrict__ ddst,
@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
                                                               T_ELEM* __restrict__ dsrc, int T, int K, int d) {
     __shared__ int first_j[GB_TILE];
     __shared__ int count[GB_TILE];
+    __shared__ int copy_list[GB_TILE];
+    __shared__ int ncopy_s;
+    static_assert(GB_TILE == 64, "one lane per row of the tile builds the copy list");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * GB_TILE;
@@ -76,11 +79,79 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
     __syncthreads();
     typedef Pack<T_ELEM, VEC> vec4;
     const int nvec = d / VEC;
+    // Rows of up to GB_FV vectors per lane (2 KB at 16-byte vectors): the tile's single-source rows are listed first, a
+    // wave requests four of them (whole rows, all loads before anything else), writes its zero rows while they are in
+    // flight and stores the copies last -- row by row in program order every copied row cost the wave one exposed
+    // round trip to HBM.
+    // The loads are inline asm: written as C++ the compiler sinks each one into the (conditional) block of its store,
+    // behind the zero stores, with a vmcnt(0) of its own.  Untracked, so the wave waits by hand before the copies.
+    constexpr int GB_FV = 2;
+    const bool fast = sizeof(vec4) == 16 && nvec <= 64 * GB_FV;
+    // Frames with several sources (in this pipeline: frame T-1 of an utterance, which the -1 pad slots address --
+    // 90 of 116 slots at MuST-C-shaped lengths) come first and are summed by the WHOLE workgroup, every wave a quarter
+    // of the columns: fp32 sum in ascending j per element (the documented order), GB_DUP source rows in flight per wave.
+    // One wave per row with four rows in flight made this row the kernel's longest chain (23 HBM round trips).
+    const int nvq = (nvec + 3) >> 2;                   // vectors per wave
+    const bool coop = nvq <= 64;
+    if (coop) {
+        const int vq = wid * nvq + lane;
+        const bool mine = lane < nvq && vq < nvec;
+        const int vc = min(vq, nvec - 1);
+        unsigned long long dup_rows = __ballot(count[lane] >= 2 && t0 + lane < T);      // one lane per row of the tile
+        while (dup_rows) {
+            const int r = __builtin_ctzll(dup_rows);
+            dup_rows &= dup_rows - 1;
+            const int t = t0 + r;
+            float acc[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+            const int jf = first_j[r];
+            for (int j0 = jf & ~63; j0 < K; j0 += 64) {
+                const int j = j0 + lane;
+                bool m = false;
+                if (j < K && j >= jf) m = (gather_frame(irow[j], T) == t);
+                unsigned long long bal = __ballot(m);
+                while (bal) {
+                    int ks[GB_DUP];
+                    const int kfirst = __builtin_ctzll(bal);
+#pragma unroll
+                    for (int u = 0; u < GB_DUP; ++u) {
+                        ks[u] = bal ? __builtin_ctzll(bal) : -1;
+                        bal &= bal - 1;          // (0 & anything stays 0)
+                    }
+                    // every load is unconditional (slots / vectors that do not exist re-read a valid address and are
+                    // dropped at the add): a branch around a load makes the compiler drain vmcnt(0) per element
+                    vec4 x[GB_DUP];
+#pragma unroll
+                    for (int u = 0; u < GB_DUP; ++u) {
+                        const int ku = ks[u] >= 0 ? ks[u] : kfirst;
+                        x[u] = ((const vec4*)(ddst + ((size_t)b * K + j0 + ku) * d))[vc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < GB_DUP; ++u)
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const float xv = (float)x[u].v[q];
+                            acc[q] += (ks[u] >= 0) ? xv : 0.0f;      // a missing slot adds +0
+                        }
+                }
+            }
+            if (mine) {
+                vec4 o;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) o.v[q] = (T_ELEM)acc[q];
+                ((vec4*)(dsrc + ((size_t)b * T + t) * d))[vq] = o;
+            }
+        }
+    }
+    // the other rows: a wave per row
     for (int r = wid; r < GB_TILE; r += 4) {
         int t = t0 + r;
         if (t >= T) break;
         vec4* out = (vec4*)(dsrc + ((size_t)b * T + t) * d);
         int c = count[r];
+        if (fast && c <= 1) continue;                  // done below
+        if (coop && c >= 2) continue;                  // done above
         if (c == 0) {
             vec4 z;
 #pragma unroll
@@ -89,64 +160,6 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
         } else if (c == 1) {
             const vec4* in = (const vec4*)(ddst + ((size_t)b * K + first_j[r]) * d);
             for (int v = lane; v < nvec; v += 64) out[v] = in[v];
-        } else if (nvec <= 64 * GB_MAXV) {
-            // duplicates (only pad slots produce them in this pipeline): fp32 sum in ascending j.  The wave finds the
-            // matching slots 64 at a time with a ballot and keeps the whole row in registers, so idx is read once.
-            float acc[GB_MAXV][VEC];
-#pragma unroll
-            for (int i = 0; i < GB_MAXV; ++i)
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[i][q] = 0.f;
-            const int jf = first_j[r];
-            for (int j0 = jf & ~63; j0 < K; j0 += 64) {
-                const int j = j0 + lane;
-                bool m = false;
-                if (j < K && j >= jf) {
-                    m = (gather_frame(irow[j], T) == t);
-                }
-                unsigned long long bal = __ballot(m);
-                // four matching rows per round: all their loads are issued before the first add (one wave owns the
-                // row, so the loads of consecutive matches must overlap or the round trips add up)
-                while (bal) {
-                    int ks[4];
-                    const int kfirst = __builtin_ctzll(bal);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ks[u] = bal ? __builtin_ctzll(bal) : -1;
-                        bal &= bal - 1;          // (0 & anything stays 0)
-                    }
-                    // every load is unconditional (rows / vectors that do not exist re-read a valid address and are
-                    // dropped at the add): a branch around a load makes the compiler drain vmcnt(0) per element
-                    vec4 x[4][GB_MAXV];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ku = ks[u] >= 0 ? ks[u] : kfirst;
-                        const vec4* in = (const vec4*)(ddst + ((size_t)b * K + j0 + ku) * d);
-#pragma unroll
-                        for (int i = 0; i < GB_MAXV; ++i) x[u][i] = in[min(lane + 64 * i, nvec - 1)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                        for (int i = 0; i < GB_MAXV; ++i)
-#pragma unroll
-                            for (int q = 0; q < VEC; ++q) {
-                                const float xv = (float)x[u][i].v[q];
-                                acc[i][q] += (ks[u] >= 0) ? xv : 0.0f;      // a missing row adds +0
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < GB_MAXV; ++i) {
-                const int v = lane + 64 * i;
-                if (v < nvec) {
-                    vec4 o;
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) o.v[q] = (T_ELEM)acc[i][q];
-                    out[v] = o;
-                }
-            }
         } else {
             // very wide rows: one vector at a time
             for (int v = lane; v < nvec; v += 64) {
@@ -163,6 +176,56 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T_ELEM* __re
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) o.v[q] = (T_ELEM)acc[q];
                 out[v] = o;
+            }
+        }
+    }
+    if (fast) {
+        if (wid == 0) {
+            const bool one = count[lane] == 1 && t0 + lane < T;
+            const unsigned long long bal = __ballot(one);
+            if (one) copy_list[__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = lane;
+            if (lane == 0) ncopy_s = __builtin_popcountll(bal);
+        }
+        __syncthreads();
+        const int ncopy = ncopy_s;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int e0 = 0; e0 < max(ncopy, 1); e0 += 16) {
+            u32x4 x[4][GB_FV];
+            int rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + wid + 4 * u;
+                // entries past the list re-read a valid row (the loads carry no branch); their store is skipped
+                const int r = ncopy > 0 ? copy_list[min(e, ncopy - 1)] : 0;
+                const int j = ncopy > 0 ? first_j[r] : 0;
+                rr[u] = e < ncopy ? r : -1;
+                const u32x4* in = (const u32x4*)(ddst + ((size_t)b * K + j) * d);
+#pragma unroll
+                for (int i = 0; i < GB_FV; ++i) {
+                    const u32x4* pv = in + min(lane + 64 * i, nvec - 1);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x[u][i]) : "v"(pv) : "memory");
+                }
+            }
+            if (e0 == 0) {
+                for (int r = wid; r < GB_TILE; r += 4) {
+                    const int t = t0 + r;
+                    if (t >= T) break;
+                    if (count[r] != 0) continue;
+                    u32x4* out = (u32x4*)(dsrc + ((size_t)b * T + t) * d);
+#pragma unroll
+                    for (int i = 0; i < GB_FV; ++i)
+                        if (lane + 64 * i < nvec) out[lane + 64 * i] = z;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (rr[u] < 0) continue;
+                u32x4* out = (u32x4*)(dsrc + ((size_t)b * T + t0 + rr[u]) * d);
+#pragma unroll
+                for (int i = 0; i < GB_FV; ++i)
+                    if (lane + 64 * i < nvec) out[lane + 64 * i] = x[u][i];
             }
         }
     }
@@ -348,8 +411,12 @@ extern "C" int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* 
     dim3 grid(cdiv(T, GB_TILE), B), block(256);
     const int esz = dtype == STAR_DT_BF16 ? 2 : 4;
     const bool v4 = (d % 4 == 0) && (((uintptr_t)ddst | (uintptr_t)dsrc) % (4 * esz) == 0);
+    const bool v8 = dtype == STAR_DT_BF16 && (d % 8 == 0) && (((uintptr_t)ddst | (uintptr_t)dsrc) % 16 == 0);
     if (dtype == STAR_DT_BF16) {
-        if (v4)
+        if (v8)
+            hipLaunchKernelGGL((gather_rows_bwd_kernel<__bf16, 8>), grid, block, 0, st, (const __bf16*)ddst, idx,
+                               (__bf16*)dsrc, T, K, d);
+        else if (v4)
             hipLaunchKernelGGL((gather_rows_bwd_kernel<__bf16, 4>), grid, block, 0, st, (const __bf16*)ddst, idx,
                                (__bf16*)dsrc, T, K, d);
         else

@@ -455,7 +455,9 @@ def test_fuzz_nugget_steps(ops):
             _step_close(scorer[0].bias.grad, b1.grad, what + " db1")
             if not simul:
                 _step_close(inp.x.grad, xr.grad, what + " dX")
-        _step_close(scorer[2].weight.grad, w2.grad, what + " dw2")
+        # dw2[n] = sum_r G'[r][n] (H[r][n] - b1[n]) from the bf16 G' (2^-9 per term): on a 40-frame utterance the terms do
+        # not average out against a max |dw2| that itself comes from cancelling terms
+        _step_close(scorer[2].weight.grad, w2.grad, what + " dw2", tol=6e-2)
         if simul:      # the select step's true db2 is 0 (the softmax is invariant under a common shift of the logits)
             # db2 = sum_r dscore[r] is one cancelling sum: measured on the scale of its sibling dw2[n] = sum_r dscore[r] h[r][n]
             _step_close(scorer[2].bias.grad, b2.grad, what + " db2", floor=float(w2.grad.abs().max()))

@@ -5,11 +5,14 @@ import torch
 from star_amd import _lib
 from star_amd.ops import DT_BF16
 B, T, K, d = 32, 1500, 116, 1024
+if len(sys.argv) > 3:
+    B, T, K = (int(v) for v in sys.argv[1:4])
+pads = [int(v) for v in sys.argv[4:]] or [0, 1, 2, 8, 58]
 dev = "cuda:0"
 g = torch.randn(B, K, d, device=dev).bfloat16()
 ds = torch.empty(B, T, d, device=dev, dtype=torch.bfloat16)
 L = _lib.lib()
-for npad in (0, 1, 2, 8, 58):
+for npad in pads:
     idx = torch.stack([torch.randperm(T - 1, device=dev)[:K].sort().values for _ in range(B)])
     if npad:
         idx[:, K - npad:] = -1
