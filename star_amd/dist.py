@@ -1,5 +1,6 @@
 """Multi-GPU: one process per GPU, utterances sharded across ranks, flat gradient all-reduces per step (the scorer's
-buffer after the step, the decoder-side buffer on a side stream as soon as the attention backward is done).
+buffer after the step, the decoder-side buffer on a side stream, one bucket per decoder layer behind that layer's
+attention backward).
 
 The reference uses Lightning's DDPStrategy over NCCL (train_w2v.py:195-196, train_simul.py:197-198): per-rank
 replicas, the batch split by the distributed sampler, bucketed gradient all-reduce during backward.  The hot

@@ -22,6 +22,7 @@ DEV = "cuda:0"
 CASES = int(os.environ.get("STAR_FUZZ_CASES", "6"))
 SEED = int(os.environ.get("STAR_FUZZ_SEED", "20261111"))
 ONLY = os.environ.get("STAR_FUZZ_ONLY")
+BIG = bool(os.environ.get("STAR_FUZZ_BIG"))
 PROGRESS = os.environ.get("STAR_FUZZ_PROGRESS")          # a file that long sweeps append a line to every 200 cases
 
 
@@ -36,7 +37,7 @@ def _cases(family):
     for n in range(CASES):
         if ONLY is not None and int(ONLY) != n:
             continue
-        if n and n % 200 == 0 and PROGRESS:          # a long sweep shows that it is alive
+        if n and n % (10 if BIG else 200) == 0 and PROGRESS:          # a long sweep shows that it is alive
             with open(PROGRESS, "a") as f:
                 f.write(f"fuzz {family}: {n}/{CASES}\n")
         yield n, np.random.default_rng([SEED, fam, n])
@@ -66,8 +67,13 @@ def test_fuzz_xattn(ops):
         B = int(rng.choice([1, 2, 3, 5, 24, 26, 33]))        # B*h >= 192 reaches the fused backward
         L = int(rng.choice([1, 7, 16, 37, 64, 100, 128, 129, 200, 257, 300]))
         K = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 200, 375, 400, 750]))
-        if B * h * L * K * hd > 3e8:                        # keep the fp32 oracle to a second or so
-            B = max(1, int(3e8 // (h * L * K * hd)))
+        lim = 3e8                                           # keeps the fp32 oracle to a second or so
+        if BIG:            # STAR_FUZZ_BIG=1: chip-filling shapes (B*h >= 192: fused / ring kernels), seconds of oracle each
+            h, B, lim = 8, int(rng.choice([24, 26, 32, 33, 40])), 4e9
+            L = int(rng.choice([37, 64, 100, 128, 129, 200, 227, 257]))
+            K = int(rng.choice([127, 128, 129, 200, 229, 375, 400, 750]))
+        if B * h * L * K * hd > lim:
+            B = max(1, int(lim // (h * L * K * hd)))
         ilk = bool(rng.integers(2))
         p = float(rng.choice([0.0, 0.0, 0.1, 0.3]))
         bias_mode = int(rng.integers(3))                     # 0: [B,K] logits, 1: none, 2: prefix bias shorter than K
