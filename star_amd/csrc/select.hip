@@ -12,8 +12,9 @@
 
 namespace star {
 
-constexpr int SEL_THREADS = 256;
+constexpr int SEL_THREADS = 1024;
 constexpr int SEL_WAVES = SEL_THREADS / 64;
+static_assert(SEL_WAVES <= 16, "the per-wave totals live in misc[16]");
 
 __device__ __forceinline__ uint32_t order_key(float f) {
     // unsigned order of the result == float order; -0.0 == +0.0; NaN ranks above everything
@@ -53,7 +54,7 @@ __device__ void radix_select(const uint32_t* keys, int T, uint32_t k, uint32_t* 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     uint32_t prefix = 0, pmask = 0, remaining = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;  // SEL_THREADS == 256 bins
+        if (tid < 256) hist[tid] = 0;  // 256 bins
         __syncthreads();
         for (int i = tid; i < T; i += SEL_THREADS) {
             uint32_t key = keys[i];
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(
         c = wave_sum(c);
         if (lane == 0) misc[wid] = (uint32_t)c;
         __syncthreads();
-        n_tok = (int)(misc[0] + misc[1] + misc[2] + misc[3]);
+        n_tok = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) n_tok += (int)misc[w];
         __syncthreads();
     } else {
         n_tok = lengths[b];
