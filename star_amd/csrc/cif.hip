@@ -8,16 +8,23 @@
 
 namespace star {
 
-constexpr int CIF_THREADS = 256;
+// 1024 threads per utterance: these kernels are chains of block-wide phases over one row of T frames, and with 256
+// threads every phase looped 6-12 times (cif_segment_kernel at T = 3000: 48 us, of which the serial scan is ~12).
+constexpr int CIF_THREADS = 1024;
+constexpr int CIF_WAVES = CIF_THREADS / 64;
 
-// block-wide sum of a double, result broadcast to every thread; red must hold >= 4 doubles.
+// block-wide sum of a double, result broadcast to every thread; red must hold >= CIF_WAVES doubles.  Every kernel
+// here sums with the same partition (thread i takes frames i, i + CIF_THREADS, ...; lanes, then waves in order).
 __device__ __forceinline__ double block_sum_f64(double v, double* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double t = red[0];
+#pragma unroll
+    for (int w = 1; w < CIF_WAVES; ++w) t += red[w];
+    return t;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -27,7 +34,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_quantity_fwd_kernel(
     const float* __restrict__ scores, const uint8_t* __restrict__ attn_mask, const int32_t* __restrict__ lengths,
     const int32_t* __restrict__ target_lengths, float threshold, int T, float* __restrict__ alphas,
     float* __restrict__ diff) {
-    __shared__ double red[4];
+    __shared__ double red[CIF_WAVES];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* srow = scores + (size_t)b * T;
     const uint8_t* mrow = attn_mask ? attn_mask + (size_t)b * T : nullptr;
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_quantity_fwd_kernel(
 
 __global__ __launch_bounds__(CIF_THREADS) void cif_quantity_loss_kernel(const float* __restrict__ diff, int B,
                                                                         float* __restrict__ loss) {
-    __shared__ double red[4];
+    __shared__ double red[CIF_WAVES];
     double acc = 0.0;
     for (int i = threadIdx.x; i < B; i += CIF_THREADS) acc += (double)diff[i] * (double)diff[i];
     double tot = block_sum_f64(acc, red);
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_kernel(const float* __
     extern __shared__ float rs_smem[];
     float* row = rs_smem;                          // [T]
     uint32_t* snap = (uint32_t*)(row + T);         // [(T+31)/32] offender snapshot bits
-    __shared__ double red[4];
+    __shared__ double red[CIF_WAVES];
     __shared__ int flag;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nwords = (T + 31) / 32;
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_resize_bwd_kernel(const float
                                                                      const int32_t* __restrict__ fixups,
                                                                      const float* __restrict__ dout, int T,
                                                                      float* __restrict__ dalphas) {
-    __shared__ double red[4];
+    __shared__ double red[CIF_WAVES];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* a = alphas + (size_t)b * T;
     const float* g = dout + (size_t)b * T;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
 // of the stand-alone kernel above (same thread partition of every sum, same recurrence), so all outputs are
 // bit-identical to cif_quantity_fwd -> cif_resize -> cif_fire_scan -> gather -> type table; it saves five launches of
 // 4-9 us each on the critical path of the step.  Prefix masks only (lengths).
-__global__ __launch_bounds__(256) void cif_segment_kernel(
+__global__ __launch_bounds__(CIF_THREADS) void cif_segment_kernel(
     const float* __restrict__ scores, const int32_t* __restrict__ lengths, const int32_t* __restrict__ target_lengths,
     float threshold, int max_rounds, int T, int cap, float* __restrict__ alphas, float* __restrict__ diff,
     float* __restrict__ resized, int32_t* __restrict__ fixups_out, int64_t* __restrict__ idx_out,
@@ -336,8 +343,8 @@ __global__ __launch_bounds__(256) void cif_segment_kernel(
     float* row = sg_smem;                          // [pitch] alphas -> resized -> pre-fire integrals
     float* thr_row = sg_smem + pitch;              // [pitch] per-frame thresholds of the scan
     uint32_t* snap = (uint32_t*)(sg_smem + 2 * pitch);   // resize: offender snapshot bits
-    __shared__ double red[4];
-    __shared__ int flag, wtot[4], slow;
+    __shared__ double red[CIF_WAVES];
+    __shared__ int flag, wtot[CIF_WAVES], slow;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = lengths[b];                      // unclamped (a length > T: every frame valid, no forced fire)
     const float* srow = scores + (size_t)b * T;
@@ -366,14 +373,15 @@ __global__ __launch_bounds__(256) void cif_segment_kernel(
     for (int round = 0; round < max_rounds; ++round) {
         if (tid == 0) flag = 0;
         __syncthreads();
-        for (int w = tid; w < nwords; w += CIF_THREADS) {
-            uint32_t bits = 0;
-            for (int k = 0; k < 32; ++k) {
-                const int i = w * 32 + k;
-                if (i < T && row[i] > threshold) bits |= 1u << k;
+        // one ballot per 64 frames (the same bits as cif_resize_kernel's word loop, without its 32-way bank conflict)
+        for (int i0 = 0; i0 < nwords * 32; i0 += CIF_THREADS) {
+            const int i = i0 + tid;
+            const unsigned long long bal = __ballot(i < T && row[i] > threshold);
+            if ((tid & 63) == 0) {
+                if ((i >> 5) < nwords) snap[i >> 5] = (uint32_t)bal;
+                if ((i >> 5) + 1 < nwords) snap[(i >> 5) + 1] = (uint32_t)(bal >> 32);
+                if (bal) flag = 1;
             }
-            snap[w] = bits;
-            if (bits) flag = 1;
         }
         __syncthreads();
         if (!flag) break;
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(256) void cif_segment_kernel(
 
     // ---- a7: fire scan on the resized row (cif_fire_scan_kernel, one row per workgroup)
     bool odd = false;
-    for (int t = tid; t < T16; t += 256) {
+    for (int t = tid; t < T16; t += CIF_THREADS) {
         float v = 0.0f;
         if (t < T) {
             const float a = row[t];
@@ -425,12 +433,12 @@ __global__ __launch_bounds__(256) void cif_segment_kernel(
         else cif_serial_chain<true>(row, thr_row, 1.0f, T16 >> 4, 0.0f);
     }
     __syncthreads();
-    const int C = (T + 255) / 256;
+    const int C = (T + CIF_THREADS - 1) / CIF_THREADS;
     const int lo = min(tid * C, T), hi = min(lo + C, T);
     int cnt = 0;
     for (int t = lo; t < hi; ++t) cnt += (row[t] >= thr_row[t]) ? 1 : 0;
     int nf;
-    int slot = block_excl_scan_256(cnt, wtot, nf);
+    int slot = block_excl_scan<CIF_WAVES>(cnt, wtot, nf);
     for (int t = lo; t < hi; ++t) {
         const bool fired = row[t] >= thr_row[t];
         if (fired) {
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) void cif_segment_kernel(
         if (max_count) atomicMax(max_count, nf);
     }
     const float last_score = srow[T - 1];
-    for (int j = nf + tid; j < cap; j += 256) {
+    for (int j = nf + tid; j < cap; j += CIF_THREADS) {
         idx_out[(size_t)b * cap + j] = -1;
         mask_out[(size_t)b * cap + j] = 0;
         scores_gather[(size_t)b * cap + j] = last_score;
@@ -622,7 +630,7 @@ extern "C" int star_cif_segment(const float* scores, const int32_t* lengths, con
             return STAR_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(cif_segment_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, scores, lengths, target_lengths,
+    hipLaunchKernelGGL(cif_segment_kernel, dim3(B), dim3(CIF_THREADS), smem, (hipStream_t)stream, scores, lengths, target_lengths,
                        threshold, max_rounds, T, cap, alphas, diff, resized, fixups_out, idx_out, mask_out, counts, max_count,
                        scores_gather, type_table, positions);
     hipLaunchKernelGGL(cif_quantity_loss_kernel, dim3(1), dim3(CIF_THREADS), 0, (hipStream_t)stream, diff, B, loss);

@@ -146,8 +146,9 @@ __device__ __forceinline__ float cif_serial_chain_unit(float* row, int nblk16, f
     return cur;
 }
 
-// exclusive scan of one int per thread over a 256-thread workgroup (wtot: 4 ints of LDS); `total` = workgroup sum
-__device__ __forceinline__ int block_excl_scan_256(int v, int* wtot, int& total) {
+// exclusive scan of one int per thread over a workgroup of NW waves (wtot: NW ints of LDS); `total` = workgroup sum
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int* wtot, int& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int incl = v;
 #pragma unroll
@@ -159,7 +160,7 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* wtot, int& total)
     __syncthreads();
     int base = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const int t = wtot[w];
         if (w < wid) base += t;
         all += t;
@@ -167,6 +168,9 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* wtot, int& total)
     __syncthreads();
     total = all;
     return base + incl - v;
+}
+__device__ __forceinline__ int block_excl_scan_256(int v, int* wtot, int& total) {
+    return block_excl_scan<4>(v, wtot, total);
 }
 
 }  // namespace star
