@@ -1044,44 +1044,61 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
     }
     __syncthreads();
     // column nl (0..127) of the block: dword (nl >> 6) * 16 + (nl & 15) of the row, bit bsh[row] - 4 * ((nl >> 4) & 3)
-    // pass 1: G' row-major, 16 B (8 columns) per thread and step
-    if (G) {
+    // pass 1: G' row-major, 16 B (8 columns) per thread and step.  A thread keeps its 8 columns over its 4 rows, so the
+    // block's column sums (fp32 ds, not the bf16 copy) come from the same bit tests: per thread over its rows, then a
+    // fixed xor tree over the 4 row groups of the wave, then the 4 waves in order through LDS.
+    float csum[8];
 #pragma unroll
-        for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
-            const int c = tid + i * 256;
-            const int row = c >> 4, cb = c & 15;                       // columns 8 cb .. 8 cb + 7
-            const uint32_t* w = brow + row * GB_PITCH + (cb >> 3) * 16 + (cb & 1) * 8;
-            const int sh = bsh[row] - 4 * ((cb >> 1) & 3);
-            const __bf16 dv = (__bf16)dsf[row];
-            bf16x8 o;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = ((w[k] >> sh) & 1u) ? dv : (__bf16)0.f;
-            *(bf16x8*)(G + (int64_t)(r0 + row) * d + n0 + cb * 8) = o;
-        }
-    }
-    // pass 2: G'^T, 16 B (8 rows of one column) per thread and step; 8 neighbouring lanes cover the 64 rows of a
-    // column, and their fp32 partial sums (lane order, then a fixed xor tree) give the block's column sum
+    for (int k = 0; k < 8; ++k) csum[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
         const int c = tid + i * 256;
-        const int nl = c >> 3, q8 = c & 7;
-        const int wofs = (nl >> 6) * 16 + (nl & 15), tsh = 4 * ((nl >> 4) & 3);
+        const int row = c >> 4, cb = c & 15;                       // columns 8 cb .. 8 cb + 7
+        const uint32_t* w = brow + row * GB_PITCH + (cb >> 3) * 16 + (cb & 1) * 8;
+        const int sh = bsh[row] - 4 * ((cb >> 1) & 3);
+        const float dvf = dsf[row];
+        const __bf16 dv = (__bf16)dvf;
         bf16x8 o;
-        float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int row = q8 * 8 + k;
-            const bool on = (brow[row * GB_PITCH + wofs] >> (bsh[row] - tsh)) & 1u;
-            const float v = dsf[row];
-            o[k] = on ? (__bf16)v : (__bf16)0.f;
-            acc += on ? v : 0.f;
+            const bool on = (w[k] >> sh) & 1u;
+            o[k] = on ? dv : (__bf16)0.f;
+            csum[k] += on ? dvf : 0.f;
         }
-        if (GT) *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (q8 == 0) colpart[(int64_t)blockIdx.x * d + n0 + nl] = acc;
+        if (G) *(bf16x8*)(G + (int64_t)(r0 + row) * d + n0 + cb * 8) = o;
     }
+    // pass 2 (NT form only): G'^T, 16 B (8 rows of one column) per thread and step
+    if (GT) {
+#pragma unroll
+        for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
+            const int c = tid + i * 256;
+            const int nl = c >> 3, q8 = c & 7;
+            const int wofs = (nl >> 6) * 16 + (nl & 15), tsh = 4 * ((nl >> 4) & 3);
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = q8 * 8 + k;
+                const bool on = (brow[row * GB_PITCH + wofs] >> (bsh[row] - tsh)) & 1u;
+                o[k] = on ? (__bf16)dsf[row] : (__bf16)0.f;
+            }
+            *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        csum[k] += __shfl_xor(csum[k], 16, 64);
+        csum[k] += __shfl_xor(csum[k], 32, 64);
+    }
+    __syncthreads();                           // every wave is done with brow: its first words take the wave partials
+    float* cpart = (float*)brow;               // [4 waves][128 columns]
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cpart[(tid >> 6) * GB_COLS + (tid & 15) * 8 + k] = csum[k];
+    }
+    __syncthreads();
+    if (tid < GB_COLS)
+        colpart[(int64_t)blockIdx.x * d + n0 + tid] =
+            ((cpart[tid] + cpart[GB_COLS + tid]) + cpart[2 * GB_COLS + tid]) + cpart[3 * GB_COLS + tid];
     if (blockIdx.y == 0 && tid < 64) {
         float v = dsf[tid];
         v = wave_sum(v);
