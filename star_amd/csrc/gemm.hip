@@ -992,6 +992,7 @@ __host__ __device__ static inline int relu_bit_pos(int64_t m, int n) {
 // forward's tile: 2 x 64 B of bits per row, staged in LDS with the row's dscore).  Memory bound: 2 * Rpad * d * 2
 // bytes written, R * d / 8 * 8 read (a row's bits share their 64-byte lines with 7 other rows).
 constexpr int GB_ROWS = 64, GB_COLS = 128, GB_PITCH = 33;      // LDS dwords per row (32 + 1: bank spread)
+constexpr int GB_NCB = 2;                                      // column blocks per workgroup
 __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __restrict__ bits, int nbn,
                                                            const float* __restrict__ ds, const int32_t* __restrict__ rows,
                                                            const int32_t* __restrict__ bit_rows, int R, int Rpad, int d,
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
                                                            __bf16* __restrict__ GT, float* __restrict__ colpart,
                                                            float* __restrict__ dspart, int nblk,
                                                            u32x4* __restrict__ zfill, int64_t zfill_n16) {
-    __shared__ uint32_t brow[GB_ROWS * GB_PITCH];
+    __shared__ uint32_t brow[GB_NCB * GB_ROWS * GB_PITCH];
     __shared__ float dsf[GB_ROWS];
     __shared__ int bsh[GB_ROWS];                   // bit position of (row, tn = 0); tn lowers it by 4
     const int tid = threadIdx.x;
@@ -1012,7 +1013,11 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
             zfill[i] = z;
         return;
     }
-    const int r0 = blockIdx.x * GB_ROWS, n0 = blockIdx.y * GB_COLS;
+    // GB_NCB column blocks of 128 per workgroup: one round trip for the row indices serves both, and twice the bytes
+    // are in flight per resident workgroup (the pass is bound by two dependent round trips per workgroup at 8
+    // workgroups per CU, not by its stores)
+    const int r0 = blockIdx.x * GB_ROWS, n00 = blockIdx.y * (GB_NCB * GB_COLS);
+    const int ncb = min(GB_NCB, (d - n00) / GB_COLS);
     // rows[r] = frame id (indexes ds); the forward's GEMM row of that frame (indexes the bits) is bit_rows[r] when the
     // forward ran on a compacted frame list, the frame id itself otherwise
     const int32_t* brows = bit_rows ? bit_rows : rows;
@@ -1022,83 +1027,99 @@ __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __res
         dsf[tid] = r < R ? dv : 0.f;
         bsh[tid] = relu_bit_pos(brows[rc], 0);
     }
-    {       // 128 B of bits per row: thread -> (row, 16-byte piece p of 8): wave column p / 4, lanes c = 4 (p % 4) .. +3
-        // both rows' loads first, without a branch around them (rows past R read row R-1's bits: their ds is 0): one
-        // memory round trip for the index loads and one for the bits, not two of each
+    {       // 128 B of bits per row and column block: thread -> (row, 16-byte piece p of 8): wave column p / 4, lanes
+        // c = 4 (p % 4) .. +3.  All loads first, without a branch around them (rows past R read row R-1's bits: their ds
+        // is 0; a column block past d re-reads the last one): one memory round trip for the index loads and one for the
+        // bits
         const int row = tid >> 3, p8 = tid & 7;
         int64_t bm[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) bm[j] = brows[min(r0 + row + 32 * j, R - 1)];
-        u32x4 v[2];
+        u32x4 v[GB_NCB][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            v[j] = *(const u32x4*)(bits + relu_bit_dword(bm[j], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
+        for (int cbk = 0; cbk < GB_NCB; ++cbk) {
+            const int n0 = n00 + min(cbk, ncb - 1) * GB_COLS;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint32_t* dstw = brow + (row + 32 * j) * GB_PITCH + p8 * 4;
-            dstw[0] = v[j][0];
-            dstw[1] = v[j][1];
-            dstw[2] = v[j][2];
-            dstw[3] = v[j][3];
+            for (int j = 0; j < 2; ++j)
+                v[cbk][j] = *(const u32x4*)(bits + relu_bit_dword(bm[j], n0 + (p8 >> 2) * 64 + (p8 & 3) * 4, nbn));
         }
+#pragma unroll
+        for (int cbk = 0; cbk < GB_NCB; ++cbk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t* dstw = brow + (cbk * GB_ROWS + row + 32 * j) * GB_PITCH + p8 * 4;
+                dstw[0] = v[cbk][j][0];
+                dstw[1] = v[cbk][j][1];
+                dstw[2] = v[cbk][j][2];
+                dstw[3] = v[cbk][j][3];
+            }
     }
     __syncthreads();
-    // column nl (0..127) of the block: dword (nl >> 6) * 16 + (nl & 15) of the row, bit bsh[row] - 4 * ((nl >> 4) & 3)
+    // column nl (0..127) of a block: dword (nl >> 6) * 16 + (nl & 15) of the row, bit bsh[row] - 4 * ((nl >> 4) & 3)
     // pass 1: G' row-major, 16 B (8 columns) per thread and step.  A thread keeps its 8 columns over its 4 rows, so the
     // block's column sums (fp32 ds, not the bf16 copy) come from the same bit tests: per thread over its rows, then a
     // fixed xor tree over the 4 row groups of the wave, then the 4 waves in order through LDS.
-    float csum[8];
+    float csum[GB_NCB][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) csum[k] = 0.f;
+    for (int cbk = 0; cbk < GB_NCB; ++cbk) {
 #pragma unroll
-    for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
-        const int c = tid + i * 256;
-        const int row = c >> 4, cb = c & 15;                       // columns 8 cb .. 8 cb + 7
-        const uint32_t* w = brow + row * GB_PITCH + (cb >> 3) * 16 + (cb & 1) * 8;
-        const int sh = bsh[row] - 4 * ((cb >> 1) & 3);
-        const float dvf = dsf[row];
-        const __bf16 dv = (__bf16)dvf;
-        bf16x8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool on = (w[k] >> sh) & 1u;
-            o[k] = on ? dv : (__bf16)0.f;
-            csum[k] += on ? dvf : 0.f;
-        }
-        if (G) *(bf16x8*)(G + (int64_t)(r0 + row) * d + n0 + cb * 8) = o;
-    }
-    // pass 2 (NT form only): G'^T, 16 B (8 rows of one column) per thread and step
-    if (GT) {
+        for (int k = 0; k < 8; ++k) csum[cbk][k] = 0.f;
+        if (cbk >= ncb) continue;
+        const int n0 = n00 + cbk * GB_COLS;
+        const uint32_t* bblk = brow + cbk * GB_ROWS * GB_PITCH;
 #pragma unroll
         for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
             const int c = tid + i * 256;
-            const int nl = c >> 3, q8 = c & 7;
-            const int wofs = (nl >> 6) * 16 + (nl & 15), tsh = 4 * ((nl >> 4) & 3);
+            const int row = c >> 4, cb = c & 15;                       // columns 8 cb .. 8 cb + 7
+            const uint32_t* w = bblk + row * GB_PITCH + (cb >> 3) * 16 + (cb & 1) * 8;
+            const int sh = bsh[row] - 4 * ((cb >> 1) & 3);
+            const float dvf = dsf[row];
+            const __bf16 dv = (__bf16)dvf;
             bf16x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int row = q8 * 8 + k;
-                const bool on = (brow[row * GB_PITCH + wofs] >> (bsh[row] - tsh)) & 1u;
-                o[k] = on ? (__bf16)dsf[row] : (__bf16)0.f;
+                const bool on = (w[k] >> sh) & 1u;
+                o[k] = on ? dv : (__bf16)0.f;
+                csum[cbk][k] += on ? dvf : 0.f;
             }
-            *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
+            if (G) *(bf16x8*)(G + (int64_t)(r0 + row) * d + n0 + cb * 8) = o;
+        }
+        // pass 2 (NT form only): G'^T, 16 B (8 rows of one column) per thread and step
+        if (GT) {
+#pragma unroll
+            for (int i = 0; i < GB_ROWS * GB_COLS / 8 / 256; ++i) {
+                const int c = tid + i * 256;
+                const int nl = c >> 3, q8 = c & 7;
+                const int wofs = (nl >> 6) * 16 + (nl & 15), tsh = 4 * ((nl >> 4) & 3);
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = q8 * 8 + k;
+                    const bool on = (bblk[row * GB_PITCH + wofs] >> (bsh[row] - tsh)) & 1u;
+                    o[k] = on ? (__bf16)dsf[row] : (__bf16)0.f;
+                }
+                *(bf16x8*)(GT + (int64_t)(n0 + nl) * Rpad + r0 + q8 * 8) = o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            csum[cbk][k] += __shfl_xor(csum[cbk][k], 16, 64);
+            csum[cbk][k] += __shfl_xor(csum[cbk][k], 32, 64);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        csum[k] += __shfl_xor(csum[k], 16, 64);
-        csum[k] += __shfl_xor(csum[k], 32, 64);
-    }
     __syncthreads();                           // every wave is done with brow: its first words take the wave partials
-    float* cpart = (float*)brow;               // [4 waves][128 columns]
+    float* cpart = (float*)brow;               // [GB_NCB][4 waves][128 columns]
     if ((tid & 63) < 16) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cpart[(tid >> 6) * GB_COLS + (tid & 15) * 8 + k] = csum[k];
+        for (int cbk = 0; cbk < GB_NCB; ++cbk)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cpart[(cbk * 4 + (tid >> 6)) * GB_COLS + (tid & 15) * 8 + k] = csum[cbk][k];
     }
     __syncthreads();
-    if (tid < GB_COLS)
-        colpart[(int64_t)blockIdx.x * d + n0 + tid] =
-            ((cpart[tid] + cpart[GB_COLS + tid]) + cpart[2 * GB_COLS + tid]) + cpart[3 * GB_COLS + tid];
+    for (int c = tid; c < ncb * GB_COLS; c += 256) {
+        const float* cp = cpart + (c >> 7) * 4 * GB_COLS + (c & 127);
+        colpart[(int64_t)blockIdx.x * d + n00 + c] = ((cp[0] + cp[GB_COLS]) + cp[2 * GB_COLS]) + cp[3 * GB_COLS];
+    }
     if (blockIdx.y == 0 && tid < 64) {
         float v = dsf[tid];
         v = wave_sum(v);
@@ -1463,8 +1484,9 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
         set_error("star_scorer_bwd: dx must be 16-byte aligned");
         return STAR_ERR_ARG;
     }
-    const int zx = zfill ? (int)cdiv((int64_t)1024, (int64_t)(d / GB_COLS)) : 0;
-    hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk + zx, d / GB_COLS), dim3(256), 0, st,
+    const int gy = cdiv(d / GB_COLS, GB_NCB);
+    const int zx = zfill ? (int)cdiv((int64_t)1024, (int64_t)gy) : 0;
+    hipLaunchKernelGGL(scorer_bwd_g_kernel, dim3(L.nblk + zx, gy), dim3(256), 0, st,
                        (const uint32_t*)relu_bits, (d + BN - 1) / BN, dscores, rows, bit_rows, (int)R, (int)Rpad, d, G, GT,
                        colpart, dspart, L.nblk, zfill ? (u32x4*)dx : nullptr, zfill ? N * d / 8 : (int64_t)0);
     if (aux != st && !tn) STAR_HIP(hipStreamWaitEvent(st, ev_join[0], 0));     // X_sel^T is ready
