@@ -988,9 +988,10 @@ __host__ __device__ static inline int relu_bit_pos(int64_t m, int n) {
 // G' = ds * relu'(H) for the R listed rows, from the forward's sign bits: G' row-major (the A operand of the dX GEMM and
 // of the TN dW1 GEMM; NULL skips it), G'^T (the A operand of the NT dW1 GEMM; NULL skips it), and per 64-row block the
 // column sums c[n] = sum_r G'[r][n]
-// (fp32 ds, not the bf16 copy) and sum_r ds[r].  One workgroup = 64 rows x 128 columns (two wave columns of the
-// forward's tile: 2 x 64 B of bits per row, staged in LDS with the row's dscore).  Memory bound: 2 * Rpad * d * 2
-// bytes written, R * d / 8 * 8 read (a row's bits share their 64-byte lines with 7 other rows).
+// (fp32 ds, not the bf16 copy) and sum_r ds[r].  One workgroup = 64 rows x GB_NCB blocks of 128 columns (a block = two
+// wave columns of the forward's tile: 2 x 64 B of bits per row, staged in LDS with the row's dscore).  Writes
+// Rpad * d * 2 bytes (twice that with G'^T), reads R * d / 8 * 8 (a row's bits share their 64-byte lines with 7
+// other rows); bound by its two dependent round trips (row ids -> bits) per workgroup, not by the stores.
 constexpr int GB_ROWS = 64, GB_COLS = 128, GB_PITCH = 33;      // LDS dwords per row (32 + 1: bank spread)
 constexpr int GB_NCB = 2;                                      // column blocks per workgroup
 __global__ __launch_bounds__(256) void scorer_bwd_g_kernel(const uint32_t* __restrict__ bits, int nbn,
