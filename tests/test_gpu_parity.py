@@ -64,7 +64,9 @@ def test_select_golden(ops, name, use_mask):
                                    g["scores_gather"])
 
 
-@pytest.mark.parametrize("B,T,rate", [(8, 1500, 4), (8, 1500, 2), (4, 1500, 12), (3, 3000, 8), (5, 257, 4), (2, 8191, 4)])
+@pytest.mark.parametrize("B,T,rate", [(8, 1500, 4), (8, 1500, 2), (4, 1500, 12), (3, 3000, 8), (5, 257, 4), (2, 8191, 4),
+                                      # around the 1024 threads of a workgroup
+                                      (3, 1023, 4), (3, 1024, 2), (2, 1025, 8), (2, 2049, 4), (4, 5, 1)])
 def test_select_random_vs_oracle(ops, B, T, rate):
     rng = np.random.default_rng(B * 1000 + T + rate)
     scores = rng.standard_normal((B, T)).astype(np.float32)

@@ -870,7 +870,8 @@ def test_fire_scan_many_utterances_and_small_cap(ops):
 
 
 # ------------------------------------------------------------------------------------------------ fused segmenter
-@pytest.mark.parametrize("B,T,frac", [(64, 1500, 0.26), (16, 3000, 1.0), (5, 333, 0.7), (3, 17, 1.0)])
+@pytest.mark.parametrize("B,T,frac", [(64, 1500, 0.26), (16, 3000, 1.0), (5, 333, 0.7), (3, 17, 1.0),
+                                      (4, 1024, 1.0), (4, 1025, 0.5), (3, 2049, 0.8), (2, 1, 1.0)])
 def test_cif_segment_equals_the_chain_of_kernels(ops, B, T, frac):
     """star_cif_segment against cif_quantity -> cif_resize -> cif_fire_scan -> gather_rows -> type_table: every output
     bit-identical, and the score gradient (quantity loss + gathered-score cotangent) equal to autograd's sum of the two."""
@@ -1159,3 +1160,31 @@ def test_scorer_backward_tn_row_range_limit(ops):
                 ops.test_override(ops.OVR_SCORER_NT, prev)
         for a, b in zip(*res):
             close(a, b, f"scorer parameter gradient at R = {R}", 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ gather backward paths
+@pytest.mark.parametrize("B,T,K,d,npad,dtype", [(3, 1500, 116, 1024, 90, torch.bfloat16),     # configs[2]-shaped pads
+                                                (2, 300, 40, 1024, 7, torch.float32),       # fp32: 16-byte vectors of 4
+                                                (2, 200, 33, 2048, 20, torch.bfloat16),     # 64 vectors per wave quarter
+                                                (2, 130, 20, 4096, 9, torch.bfloat16),      # rows too wide for the fast paths
+                                                (2, 90, 17, 100, 5, torch.bfloat16),        # 8-byte vectors
+                                                (4, 64, 64, 128, 0, torch.bfloat16)])       # every frame of a tile taken once
+def test_gather_backward_paths_bit_exact(ops, B, T, K, d, npad, dtype):
+    """Row-gather backward: single-source rows (listed, loads in flight across the zero stores), frames with many
+    sources (summed by the whole workgroup) and untouched frames, each path and vector width: equal, bit for bit, to
+    the fp32 sum in ascending slot order rounded once (the documented rule)."""
+    g = torch.Generator().manual_seed(B * T + K + d)
+    idx = torch.stack([torch.randperm(T, generator=g)[:K].sort().values for _ in range(B)])
+    if npad:
+        idx[:, K - npad:] = -1                       # pad slots: all of them address frame T - 1
+        idx[0, 1] = idx[0, 0]                        # and one ordinary duplicate
+    src = torch.zeros(B, T, d, dtype=dtype, device=DEV, requires_grad=True)
+    out = ops.gather_rows(src, idx.to(DEV))
+    gout = torch.randn(B, K, d, generator=g).to(dtype)
+    out.backward(gout.to(DEV))
+    acc = torch.zeros(B, T, d, dtype=torch.float32)
+    tgt = torch.where(idx < 0, idx + T, idx)
+    for b in range(B):
+        for j in range(K):                           # ascending slot order
+            acc[b, tgt[b, j]] += gout[b, j].float()
+    assert torch.equal(src.grad.cpu(), acc.to(dtype))
