@@ -1,7 +1,7 @@
 """Randomised parity sweep: random shapes / lengths / switches for every kernel family against the CPU oracle.
 
 The parametrised tests pin the shapes that matter (the configs, the kernels' dispatch boundaries); this file walks the
-space between them.  STAR_FUZZ_CASES cases per family (default 6, so the suite stays short; a sweep is
+space between them.  STAR_FUZZ_CASES cases per family (default 24, so the suite stays short; a sweep is
 `STAR_FUZZ_CASES=300 STAR_FUZZ_SEED=... pytest tests/test_gpu_fuzz.py`), every case seeded by (STAR_FUZZ_SEED, family,
 case number) and named in the failure message, so that a failing case can be replayed alone with STAR_FUZZ_ONLY=<n>.
 Bars as in test_gpu_parity.py: integer work bit-exact, bf16-MFMA work 2e-2 of the tensor's scale against the fp32
@@ -19,7 +19,7 @@ from tests.test_oracle_golden import lmask
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-CASES = int(os.environ.get("STAR_FUZZ_CASES", "6"))
+CASES = int(os.environ.get("STAR_FUZZ_CASES", "24"))
 SEED = int(os.environ.get("STAR_FUZZ_SEED", "20261111"))
 ONLY = os.environ.get("STAR_FUZZ_ONLY")
 BIG = bool(os.environ.get("STAR_FUZZ_BIG"))
