@@ -93,16 +93,6 @@ int star_gather_rows_fwd(const void* src, const int64_t* idx, void* dst, int B, 
 int star_gather_rows_bwd(const void* ddst, const int64_t* idx, void* dsrc, int B, int T, int K,
                          int d, int dtype, void* stream);
 
-/* Diagonal K/V fan-out.  NOT a reference operator: the NuggetStep harness derives the
- * per-layer K_l / V_l from the gathered memory with a fixed diagonal linear map standing in for the c_attn
- * GEMM (row a9, left to hipBLASLt); these two kernels keep that stand-in at one pass over the data.
- *   fwd: out[j][r][:] = mem[r][:] * scales[j][:]      mem [R,d], scales [J,d], out [J,R,d], all bf16, J <= 16
- *   bwd: dmem[r][:]   = sum_j grads[j][r][:] * scales[j][:]   (fp32 accumulate); grads_host is a HOST array
- *        of J device pointers, each a dense [R,d] bf16 buffer. */
-int star_diag_fanout_fwd(const void* mem, const void* scales, int J, int64_t R, int d, void* out, void* stream);
-int star_diag_fanout_bwd(const void* const* grads_host, int J, const void* scales, int64_t R, int d, void* dmem,
-                         void* stream);
-
 /* ---------------------------------------------------------------- f-3 (second half): gather at the output of the
  * semantic encoder.  The reference normalises all T frames with the encoder's final LayerNorm (ln_f,
  * my_transformer.py:945) and then keeps the nugget rows (w2v_asr.py:566-567, w2v_simul.py:446-447); LayerNorm is
@@ -289,7 +279,9 @@ int star_scorer_fwd_compact(const void* x, const void* w1, const float* b1, cons
  * Limit: star_scorer_fwd_workspace(N, d) <= STAR_SCORER_STATIC_SCRATCH_BYTES, i.e. N <= 262,144 frames at d = 1024;
  * larger inputs return STAR_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array: calls that overlap in time
  * on one GPU (two streams, two threads) race -- serialise them or use star_scorer_fwd.  Same kernels and the same
- * bits as star_scorer_fwd. */
+ * bits as star_scorer_fwd.  Device rule: the scratch pointer is the one of the CURRENT device, and `stream` (when
+ * non-NULL) must belong to that device -- a stream of another device is refused with STAR_ERR_ARG (each GPU holds its
+ * own copy of the array at its own address). */
 #define STAR_SCORER_STATIC_SCRATCH_BYTES (4u << 20)
 int star_scorer_fwd_static(const void* x, const void* w1, const float* b1, const float* w2, const float* b2,
                            int64_t N, int d, float* scores, void* relu_bits, void* stream);

@@ -369,18 +369,26 @@ def cif_aggregate(alphas: torch.Tensor, s: torch.Tensor, threshold: float = 1.0)
 
 
 # ------------------------------------------------------------------ composite step (bench/smoke)
-def nugget_step_asr(x, s_repr, lengths, rate, w1, b1, w2, b2, qs, kv_scales, gs):
+def nugget_step_asr(x, s_repr, lengths, rate, w1, b1, w2, b2, qs, kv_scales, gs, select=None):
     """One NuggetStep of the non-streaming path, fp32 on CPU.
 
     x [B,T,d] scorer input, s_repr [B,T,d] semantic states, lengths list[int], qs list of
     [B,h,L,hd] queries (one per layer), kv_scales list of (ak[d], av[d]) fixed diagonal K/V
     maps, gs list of cotangents like qs.  Returns dict with scores, indices, loss.
+
+    select = (nugget_mask, indices) replaces the oracle's own selection (a test passes the kernel's, which it has
+    checked bit for bit against topk_select on the kernel's own scores, so that a near-tie resolved differently by the
+    bf16 and the fp32 scorer cannot hide everything downstream); "own_indices" always holds the oracle's.
     """
     bsz, t, d = x.shape
     h = qs[0].shape[1]
     mask = torch.arange(t)[None, :] < torch.tensor(lengths)[:, None]
     scores = scorer(x, w1, b1, w2, b2)
     nmask, idx, _ = topk_select(scores.detach().numpy(), mask.numpy(), rate)
+    own_idx = idx
+    if select is not None:
+        nmask, idx = (np.asarray(v) for v in select)
+        nmask, idx = nmask.astype(bool), idx.astype(np.int64)
     idx_t = torch.from_numpy(idx)
     nmask_t = torch.from_numpy(nmask)
     sg = scores.gather(1, idx_t)
@@ -392,7 +400,7 @@ def nugget_step_asr(x, s_repr, lengths, rate, w1, b1, w2, b2, qs, kv_scales, gs)
         vv = (mem * av).view(bsz, -1, h, d // h).transpose(1, 2)
         o, _ = xattn_core(q, kk, vv, nmask_t, sg, False)
         loss = loss + (o * g).sum()
-    return {"scores": scores, "indices": idx, "mask": nmask, "table": table, "positions": pos,
+    return {"scores": scores, "indices": idx, "own_indices": own_idx, "mask": nmask, "table": table, "positions": pos,
             "scores_gather": sg, "mem": mem, "loss": loss}
 
 
@@ -430,3 +438,91 @@ def nugget_step_simul(x, s_repr, lengths, target_lengths, use_ilk, w1, b1, w2, b
     return {"scores": scores, "alphas": alphas, "resized": resized, "quantity_loss": qloss, "indices": idx,
             "mask": nmask, "table": table, "positions": pos, "scores_gather": sg, "mem": mem,
             "loss": loss + 0.01 * qloss}
+
+
+# ------------------------------------------------------------------ configs[0]: the whole-decoder CPU step (timing only)
+class DecoderStepConfig0:
+    """CPU timing stand-in for BASELINE.json configs[0] as the survey measured it on the reference (SURVEY.md section
+    6 and 8d: scorer, select, gather, then the WHOLE lm_decoder forward + backward, 124.3 ms on 8 threads): the
+    NuggetStep pieces above inside a GPT-2-shaped decoder with the reference's configuration (w2v_asr.py:134-145:
+    n_head 8, n_positions 512, add_cross_attention; BASELINE configs[0]: 6 layers, vocabulary 10 000) and block
+    structure (my_transformer.py:686-750: ln_1, causal self-attention, ln_cross_attn, score-biased cross-attention,
+    ln_2, MLP; :945 ln_f; :1041-1058 classifier + shifted cross-entropy).  Used ONLY by bench.py's cpu_baseline leg
+    for `--config 0`; no parity claim rests on it (the decoder scaffolding is outside the hot path; its cross-attention
+    core is xattn_core above, which is pinned).  Calling the object runs one forward + backward."""
+
+    def __init__(self, lengths, t, d, h, l_tgt, nl, rate, vocab=10000, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.lengths, self.rate, self.h, self.nl, self.d = list(lengths), rate, h, nl, d
+        bsz = len(lengths)
+        self.x = torch.randn(bsz, t, d, generator=g).requires_grad_()
+        self.s = torch.randn(bsz, t, d, generator=g).requires_grad_()
+        self.ids = torch.randint(0, vocab, (bsz, l_tgt), generator=g)
+
+        def p(*shape, std=0.02):
+            return (torch.randn(*shape, generator=g) * std).requires_grad_()
+        lim = 1 / d ** 0.5
+        self.scorer = [((torch.rand(d, d, generator=g) * 2 - 1) * lim).requires_grad_(),
+                       ((torch.rand(d, generator=g) * 2 - 1) * lim).requires_grad_(),
+                       ((torch.rand(1, d, generator=g) * 2 - 1) * lim).requires_grad_(),
+                       ((torch.rand(1, generator=g) * 2 - 1) * lim).requires_grad_()]
+        self.wte, self.wpe = p(vocab, d), p(512, d)
+        self.layers = []
+        for _ in range(nl):
+            self.layers.append(dict(
+                ln1=(torch.ones(d).requires_grad_(), torch.zeros(d).requires_grad_()),
+                attn_w=p(d, 3 * d), attn_b=torch.zeros(3 * d).requires_grad_(),
+                attn_pw=p(d, d), attn_pb=torch.zeros(d).requires_grad_(),
+                lnx=(torch.ones(d).requires_grad_(), torch.zeros(d).requires_grad_()),
+                q_w=p(d, d), q_b=torch.zeros(d).requires_grad_(),
+                kv_w=p(d, 2 * d), kv_b=torch.zeros(2 * d).requires_grad_(),
+                x_pw=p(d, d), x_pb=torch.zeros(d).requires_grad_(),
+                ln2=(torch.ones(d).requires_grad_(), torch.zeros(d).requires_grad_()),
+                fc_w=p(d, 4 * d), fc_b=torch.zeros(4 * d).requires_grad_(),
+                fc2_w=p(4 * d, d), fc2_b=torch.zeros(d).requires_grad_()))
+        self.lnf = (torch.ones(d).requires_grad_(), torch.zeros(d).requires_grad_())
+        self.cls_w, self.cls_b = p(d, vocab), torch.zeros(vocab).requires_grad_()
+
+    def _leaves(self):
+        out = [self.x, self.s, self.wte, self.wpe, self.cls_w, self.cls_b, *self.scorer, *self.lnf]
+        for lay in self.layers:
+            for v in lay.values():
+                out.extend(v if isinstance(v, tuple) else [v])
+        return out
+
+    def __call__(self):
+        ln = torch.nn.functional.layer_norm
+        for t in self._leaves():
+            t.grad = None
+        bsz, t, d = self.x.shape
+        h, hd = self.h, d // self.h
+        mask = torch.arange(t)[None, :] < torch.tensor(self.lengths)[:, None]
+        scores = scorer(self.x, *self.scorer)
+        nmask, idx, _ = topk_select(scores.detach().numpy(), mask.numpy(), self.rate)
+        idx_t, nmask_t = torch.from_numpy(idx), torch.from_numpy(nmask)
+        sg = scores.gather(1, idx_t)
+        mem = gather_rows(self.s, idx_t)
+        lt = self.ids.shape[1]
+        hid = self.wte[self.ids] + self.wpe[:lt][None]
+        causal = torch.tril(torch.ones(lt, lt, dtype=torch.bool))
+
+        def heads(u):
+            return u.view(bsz, -1, h, hd).transpose(1, 2)
+        for lay in self.layers:
+            a = ln(hid, (d,), *lay["ln1"])
+            q, k, v = (a @ lay["attn_w"] + lay["attn_b"]).split(d, dim=2)
+            att = heads(q) @ heads(k).transpose(-1, -2) / hd ** 0.5
+            att = torch.softmax(att.masked_fill(~causal, F32_MIN), dim=-1)
+            hid = hid + ((att @ heads(v)).transpose(1, 2).reshape(bsz, lt, d) @ lay["attn_pw"] + lay["attn_pb"])
+            a = ln(hid, (d,), *lay["lnx"])
+            q = a @ lay["q_w"] + lay["q_b"]
+            k, v = (mem @ lay["kv_w"] + lay["kv_b"]).split(d, dim=2)
+            o, _ = xattn_core(heads(q), heads(k), heads(v), nmask_t, sg, False)
+            hid = hid + (o.transpose(1, 2).reshape(bsz, lt, d) @ lay["x_pw"] + lay["x_pb"])
+            a = ln(hid, (d,), *lay["ln2"])
+            hid = hid + (torch.nn.functional.gelu(a @ lay["fc_w"] + lay["fc_b"], approximate="tanh") @ lay["fc2_w"]
+                         + lay["fc2_b"])
+        logits = ln(hid, (d,), *self.lnf) @ self.cls_w + self.cls_b
+        loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), self.ids[:, 1:].reshape(-1))
+        loss.backward()
+        return loss

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
                 const bool valid = attn_mask ? (attn_mask[base + t] != 0) : (t < n_r);
                 v = valid ? a : a * 0.0f;                  // alphas * attn_mask (keeps NaN/inf of the product)
                 c += valid ? 1 : 0;
-                odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v <= 1.0f));
+                odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v < 1.0f));
             }
             fs_rows[r * pitch + t] = v;
         }
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_segment_kernel(
             const float a = row[t];
             resized[(size_t)b * T + t] = a;
             v = (t < n) ? a : a * 0.0f;                    // resized * mask (keeps NaN / inf of the product)
-            odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v <= 1.0f));
+            odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v < 1.0f));
         }
         row[t] = v;
         thr_row[t] = t >= T ? __builtin_inff() : ((n == t + 1) ? -__builtin_inff() : 1.0f);

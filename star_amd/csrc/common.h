@@ -116,9 +116,12 @@ __device__ __forceinline__ float cif_serial_chain(float* row, const float* thr_r
     return cur;
 }
 
-// The same chain for the common case -- threshold 1 on every frame, every weight in {0} u [FLT_MIN, 1], carry in
-// {0} u [FLT_MIN, 1): then I = cur + a lies in [0, 2), and "I >= 1 ? I - 1 : I" is fract(I) EXACTLY (I - 1 is exact
-// for I in [1, 2) by Sterbenz, no denormal can appear).  Two dependent instructions per frame (v_add_f32, v_fract_f32)
+// The same chain for the common case -- threshold 1 on every frame, every weight in {0} u [FLT_MIN, 1) (1.0 itself
+// EXCLUDED), carry in {0} u [FLT_MIN, 1): then I = cur + a <= 2 - 2^-23 is formed without rounding up to 2, lies in
+// [0, 2), and "I >= 1 ? I - 1 : I" is fract(I) EXACTLY (I - 1 is exact for I in [1, 2) by Sterbenz, no denormal can
+// appear).  With a weight of exactly 1.0 and a carry of 1 - 2^-24 the sum would round (ties to even) to 2.0, where the
+// reference keeps a carry of 1.0 and fires again on the next frame while fract(2.0) = 0 does not: rows that hold an
+// exact 1.0 therefore take the generic chain above.  Two dependent instructions per frame (v_add_f32, v_fract_f32)
 // instead of four.  The caller checks the precondition; a forced fire (threshold -inf) is legal only where every later
 // weight is zero, where the two recurrences can no longer produce different fires.
 __device__ __forceinline__ float cif_serial_chain_unit(float* row, int nblk16, float cur) {

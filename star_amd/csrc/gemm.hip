@@ -1224,13 +1224,31 @@ constexpr size_t STATIC_SCRATCH_BYTES = STAR_SCORER_STATIC_SCRATCH_BYTES;
 static __device__ __align__(256) unsigned char scratch[star::STATIC_SCRATCH_BYTES];
 namespace star {
 static std::atomic<void*> g_scratch_ptr[64];
-// device address of `scratch` on the CURRENT device (looked up once per device, with that device current)
-static void* static_scratch(int* rc) {
+// device address of `scratch` on the CURRENT device (looked up once per device, with that device current).  Every
+// GPU holds its own copy of the array at its own address, so the pointer must belong to the device the kernels will
+// run on: the stream's.  A stream of another device than the current one is refused (the library launches on the
+// current device, as every other entry point does; a caller that switches devices makes the stream's device current).
+static void* static_scratch(int* rc, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
         set_error("star_scorer_fwd_static: cannot identify the current device");
         *rc = STAR_ERR_LAUNCH;
         return nullptr;
+    }
+    if (stream) {
+        int sdev = dev;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("star_scorer_fwd_static: cannot identify the stream's device");
+            *rc = STAR_ERR_ARG;
+            return nullptr;
+        }
+        if (sdev != dev) {
+            set_error("star_scorer_fwd_static: the stream belongs to device %d but device %d is current: make the "
+                      "stream's device current before the call", sdev, dev);
+            *rc = STAR_ERR_ARG;
+            return nullptr;
+        }
     }
     void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
     if (!ptr) {
@@ -1350,7 +1368,7 @@ extern "C" int star_scorer_fwd_static(const void* x, const void* w1, const float
         return STAR_ERR_WORKSPACE;
     }
     int rc = STAR_OK;
-    void* ptr = static_scratch(&rc);
+    void* ptr = static_scratch(&rc, (hipStream_t)stream);
     if (!ptr) return rc;
     // every partial the finish kernel reads is written by the GEMM of THIS call: nothing has to start at zero
     return star_scorer_fwd(x, w1, b1, w2, b2, N, d, scores, relu_bits, ptr, STATIC_SCRATCH_BYTES, stream);

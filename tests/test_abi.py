@@ -1,5 +1,6 @@
 """CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol that
-include/star_nugget.h declares, and the ctypes table mirrors the header (no compute calls: no GPU here)."""
+include/*.h declare (star_nugget.h = the product ABI, star_harness.h = the harness-only fan-out stand-in), and the
+ctypes table mirrors the headers (no compute calls: no GPU here)."""
 import ctypes
 import os
 import re
@@ -7,13 +8,22 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "star_nugget.h")
+HEADERS = [os.path.join(ROOT, "include", n) for n in ("star_nugget.h", "star_harness.h")]
 
 
-def declared_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(star_[a-z0-9_]+)\s*\(", text)))
+def declared_functions(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(star_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_harness_stand_in_is_not_in_the_product_header():
+    product = declared_functions(HEADERS[:1])
+    assert not [n for n in product if "fanout" in n]
+    assert declared_functions(HEADERS[1:]) == ["star_diag_fanout_bwd", "star_diag_fanout_fwd"]
 
 
 def test_header_declares_the_expected_entry_points():

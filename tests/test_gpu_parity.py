@@ -768,25 +768,27 @@ def test_nugget_step_asr_vs_oracle(ops):
     w1r = bf16_round(w1.detach()).requires_grad_()
     xr, sr = cpu(inp.x).requires_grad_(), cpu(inp.s).requires_grad_()
     qs = [cpu(q).requires_grad_() for q in inp.qs]
+    # the oracle step runs on the kernel's selection (bit-exact above on the kernel's own scores), so that a near-tie
+    # resolved differently by the fp32 scorer cannot skip the comparison of everything downstream
     ref = orc.nugget_step_asr(xr, sr, lengths, rate, w1r, b1, w2, b2, qs, [(cpu(a), cpu(b)) for a, b in inp.kv_scales],
-                              [cpu(g) for g in inp.gs])
+                              [cpu(g) for g in inp.gs], select=(o_mask, o_idx))
     # the step scores a ragged batch through star_scorer_fwd_ragged: pad frames (masked by every consumer) are 0
     np.testing.assert_allclose(scores[mask], ref["scores"].detach().numpy()[mask], rtol=2e-3, atol=2e-3)
     assert (scores[~mask] == 0).all()
-    if np.array_equal(ref["indices"], o_idx):           # same selection -> compare everything downstream
-        ref["loss"].backward()
-        assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-2 * abs(ref["loss"].item()) + 1e-2
+    assert (ref["own_indices"] != o_idx).sum() <= 8
+    ref["loss"].backward()
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-2 * abs(ref["loss"].item()) + 1e-2
 
-        def close(a, b, what, tol=3e-2):
-            a, b = a.float().cpu().numpy(), b.numpy()
-            scale = np.abs(b).max() + 1e-12
-            assert np.abs(a - b).max() <= tol * scale, f"{what}: {np.abs(a - b).max()} vs scale {scale}"
-        close(scorer[0].weight.grad, w1r.grad, "dW1")
-        close(scorer[2].weight.grad, w2.grad, "dw2")
-        close(scorer[0].bias.grad, b1.grad, "db1")
-        close(inp.s.grad, sr.grad, "dS")
-        close(inp.qs[0].grad, qs[0].grad, "dQ0")
-        close(inp.x.grad, xr.grad, "dX")
+    def close(a, b, what, tol=3e-2):
+        a, b = a.float().cpu().numpy(), b.numpy()
+        scale = np.abs(b).max() + 1e-12
+        assert np.abs(a - b).max() <= tol * scale, f"{what}: {np.abs(a - b).max()} vs scale {scale}"
+    close(scorer[0].weight.grad, w1r.grad, "dW1")
+    close(scorer[2].weight.grad, w2.grad, "dw2")
+    close(scorer[0].bias.grad, b1.grad, "db1")
+    close(inp.s.grad, sr.grad, "dS")
+    close(inp.qs[0].grad, qs[0].grad, "dQ0")
+    close(inp.x.grad, xr.grad, "dX")
 
 
 def test_nugget_step_simul_runs_and_matches_oracle_pieces(ops):
