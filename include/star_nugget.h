@@ -174,7 +174,9 @@ int star_cif_segment(const float* scores, const int32_t* lengths, const int32_t*
  *   alpha_chunk [B,Tc] fp32    the next Tc frames of every utterance (frames at or beyond the utterance's length
  *                              count as masked: weight 0)
  *   lengths     [B] int32      utterance lengths in ABSOLUTE frames; the frame lengths[b]-1 always fires.  While an
- *                              utterance's end is not known yet pass INT32_MAX
+ *                              utterance's end is not known yet pass INT32_MAX.  The forced fire is only emitted when
+ *                              the length is known IN the call whose chunk holds frame lengths[b]-1: a length that
+ *                              arrives later is not acted upon here (star_cif_stream_push has the late flush)
  *   score_chunk optional [B,Tc] fp32 scorer logits of the chunk: scores_gather[b,j] = score at the j-th fire
  *   state_cur   [B] fp32  in/out  integrator carry (0 before the first chunk)
  *   state_pos   [B] int32 in/out  frames consumed so far (0 before the first chunk; += Tc per call)
@@ -183,6 +185,29 @@ int star_cif_segment(const float* scores, const int32_t* lengths, const int32_t*
 int star_cif_fire_step(const float* alpha_chunk, const int32_t* lengths, const float* score_chunk, int B,
                        int Tc, float* state_cur, int32_t* state_pos, int cap, int64_t* idx_out,
                        int32_t* counts, float* scores_gather, void* stream);
+/* The streaming segmenter's whole per-chunk tail in ONE launch (no call site in the
+ * reference, which segments whole utterances, w2v_simul.py:419-447): alphas = sigmoid(score) * mask (:420-421, the
+ * bits of star_cif_quantity_fwd), the fire recurrence of star_cif_fire_step, and the append of every fired frame's
+ * semantic row (:446-447), scorer logit (:427, the attention bias) and absolute position to the utterance's nugget
+ * memory at counts[b].  Any chunking gives the memory of the offline kernels bit for bit.
+ *   score_chunk [B,Tc] fp32   scorer logits of the chunk      s_chunk [B,Tc,d] (dtype) semantic states of the chunk
+ *   lengths     [B] int32     utterance lengths in absolute frames, INT32_MAX while unknown.  The end of an utterance
+ *                             must become known no later than the call AFTER the one whose chunk ends with its last
+ *                             frame (lengths[b] == frames consumed): the forced fire of that frame is then emitted
+ *                             from the saved row (a "late flush").  Frames pushed as valid beyond an end that is
+ *                             announced later cannot be taken back.  Tc == 0: the flush alone (end of a stream).
+ *   state_cur [B] fp32, state_pos [B] int32, state_last [B] int32 (position of the newest fire, start at -1): in/out
+ *   mem [B,kmax,d] (dtype), mem_scores [B,kmax] fp32, mem_pos [B,kmax] int64, counts [B] int32 (in/out, <= kmax),
+ *   dropped [B] int32 (in/out): fires that found no slot because the memory was full -- poll it, a non-zero entry
+ *   means the memory of that utterance is truncated;  last_row [B,d] (dtype), last_score [B] fp32: scratch state.
+ *   idx_out [B,cap] int64 / cnt_out [B] int32 (both optional): this chunk's fires as star_cif_fire_step reports them
+ *   (the late-flush fire is not listed).  d * sizeof(dtype) must be a multiple of 16, buffers 16-byte aligned,
+ *   Tc <= 8192. */
+int star_cif_stream_push(const float* score_chunk, const void* s_chunk, int dtype, const int32_t* lengths,
+                         int B, int Tc, int d, float* state_cur, int32_t* state_pos, int32_t* state_last,
+                         int kmax, void* mem, float* mem_scores, int64_t* mem_pos, int32_t* counts,
+                         int32_t* dropped, void* last_row, float* last_score, int cap, int64_t* idx_out,
+                         int32_t* cnt_out, void* stream);
 /* block_attn_mask[b,i,j] = 1.0f iff prev_fire(i) < j <= i and frame i valid (w2v_simul.py:382-402),
  * built on demand from the fire positions.  idx [B,cap] int64 (-1 padded), counts [B] int32,
  * out [B,T,T] fp32. */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "star_cif_fire_scan": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_segment": (_I, [_P, _P, _P, _F, _I, _I, _I, _I] + [_P] * 12 + [_P]),
     "star_cif_fire_step": (_I, [_P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "star_cif_stream_push": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "star_cif_block_mask": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "star_cif_weights": (_I, [_P, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "star_cif_aggregate_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

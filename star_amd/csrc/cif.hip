@@ -466,6 +466,139 @@ __global__ __launch_bounds__(CIF_THREADS) void cif_segment_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------ f4: one launch per chunk
+// The streaming segmenter's whole per-chunk tail in ONE kernel, one workgroup per
+// utterance: alphas = sigmoid(score) * mask (w2v_simul.py:420-421, the expression of cif_quantity_fwd_kernel, so the
+// weights are the same bits), the fire recurrence carried across chunks (cif_fire_scan_kernel's streaming form), and
+// the append of the fired semantic rows, their scorer logits (w2v_simul.py:427: the attention bias) and their absolute
+// positions (w2v_simul.py:446-447) to the utterance's memory at counts[b].  Tc == 0 runs the end-of-utterance flush
+// only.  Row copies are 16 bytes per lane (the host checks d * esize % 16 == 0 and the alignment).
+struct StreamMem {
+    unsigned char* mem;        // [B][kmax][row_bytes]
+    float* mem_scores;         // [B][kmax]
+    int64_t* mem_pos;          // [B][kmax]
+    int32_t* counts;           // [B] in/out, never above kmax
+    int32_t* dropped;          // [B] in/out: fires that found no slot
+    unsigned char* last_row;   // [B][row_bytes]: the newest frame's semantic row (what a late flush appends)
+    float* last_score;         // [B]
+    int32_t* state_last;       // [B] in/out: absolute position of the newest fire, -1 = none yet
+    int kmax;
+    int row_bytes;
+};
+
+__device__ __forceinline__ void stream_copy_row(unsigned char* dst, const unsigned char* src, int row_bytes, int lane) {
+    for (int o = lane * 16; o < row_bytes; o += 64 * 16) *(u32x4*)(dst + o) = *(const u32x4*)(src + o);
+}
+
+__global__ __launch_bounds__(256) void cif_stream_push_kernel(
+    const float* __restrict__ scores, const unsigned char* __restrict__ s_chunk, const int32_t* __restrict__ lengths,
+    int Tc, float* __restrict__ state_cur, int32_t* __restrict__ state_pos, StreamMem m, int cap,
+    int64_t* __restrict__ idx_out, int32_t* __restrict__ cnt_out) {
+    extern __shared__ __attribute__((aligned(16))) float sp_smem[];
+    const int pitch = scan_pitch(Tc), T16 = (Tc + 15) & ~15;
+    float* row = sp_smem;                       // [pitch] alphas -> pre-fire integrals
+    float* thr_row = sp_smem + pitch;           // [pitch]
+    int* fire_list = (int*)(sp_smem + 2 * pitch);   // [Tc] chunk-relative fire positions, ascending
+    __shared__ int wtot[4], slow;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pos0 = state_pos[b];
+    const int len = lengths[b];
+    int c0 = m.counts[b];
+    int last = m.state_last[b];
+    float cur0 = state_cur[b];
+    int lost = 0;
+    if (tid == 0) slow = 0;
+    __syncthreads();
+    // ---- the end of the utterance became known only AFTER its last frame was pushed (len == frames consumed): the
+    // forced fire of that frame (w2v_simul.py:388, src_len == i + 1) is emitted now from the saved row, unless the
+    // frame fired by itself
+    if (len == pos0 && pos0 > 0 && last != len - 1) {
+        if (c0 < m.kmax) {
+            if (wid == 0)
+                stream_copy_row(m.mem + ((size_t)b * m.kmax + c0) * m.row_bytes, m.last_row + (size_t)b * m.row_bytes,
+                                m.row_bytes, lane);
+            if (tid == 0) {
+                m.mem_scores[(size_t)b * m.kmax + c0] = m.last_score[b];
+                m.mem_pos[(size_t)b * m.kmax + c0] = (int64_t)len - 1;
+            }
+            ++c0;
+        } else {
+            ++lost;
+        }
+        last = len - 1;
+        cur0 = __fsub_rn(cur0, 1.0f);           // the reference subtracts 1 at every fire, forced or not
+    }
+    int nf = 0;
+    if (Tc > 0) {
+        const float* srow = scores + (size_t)b * Tc;
+        // frames of this chunk inside the utterance: [0, n)
+        const int n = (int)max(min((int64_t)len - pos0, (int64_t)Tc), (int64_t)0);
+        const int64_t rel = (int64_t)len - pos0;                       // forced fire at chunk frame rel - 1
+        bool odd = false;
+        for (int t = tid; t < T16; t += 256) {
+            float v = 0.0f;
+            if (t < n) v = 1.0f / (1.0f + expf(-srow[t]));             // cif_quantity_fwd_kernel's expression
+            odd |= !(v == 0.0f || (v >= 1.17549435e-38f && v < 1.0f));
+            row[t] = v;
+            thr_row[t] = t >= Tc ? __builtin_inff() : ((rel == (int64_t)t + 1) ? -__builtin_inff() : 1.0f);
+        }
+        if (odd) slow = 1;
+        __syncthreads();
+        if (tid == 0) {
+            const bool unit = !slow && (cur0 == 0.0f || (cur0 >= 1.17549435e-38f && cur0 < 1.0f));
+            float c1;
+            if (unit) {
+                c1 = cif_serial_chain_unit(row, T16 >> 4, cur0);
+                if (rel >= 1 && rel <= Tc) c1 = __fsub_rn(row[rel - 1], 1.0f);
+            } else {
+                c1 = cif_serial_chain<true>(row, thr_row, 1.0f, T16 >> 4, cur0);
+            }
+            state_cur[b] = c1;
+        }
+        __syncthreads();
+        const int C = (Tc + 255) / 256;
+        const int lo = min(tid * C, Tc), hi = min(lo + C, Tc);
+        int cnt = 0;
+        for (int t = lo; t < hi; ++t) cnt += (row[t] >= thr_row[t]) ? 1 : 0;
+        int slot = block_excl_scan_256(cnt, wtot, nf);
+        for (int t = lo; t < hi; ++t)
+            if (row[t] >= thr_row[t]) fire_list[slot++] = t;
+        __syncthreads();
+        // ---- append: one wave per fired row
+        for (int j = wid; j < nf; j += 4) {
+            const int t = fire_list[j];
+            const int dest = c0 + j;
+            if (dest < m.kmax) {
+                stream_copy_row(m.mem + ((size_t)b * m.kmax + dest) * m.row_bytes,
+                                s_chunk + ((size_t)b * Tc + t) * m.row_bytes, m.row_bytes, lane);
+                if (lane == 0) {
+                    m.mem_scores[(size_t)b * m.kmax + dest] = srow[t];
+                    m.mem_pos[(size_t)b * m.kmax + dest] = (int64_t)pos0 + t;
+                }
+            }
+        }
+        if (idx_out) {
+            for (int j = tid; j < cap; j += 256) idx_out[(size_t)b * cap + j] = j < nf ? (int64_t)pos0 + fire_list[j] : -1;
+        }
+        // the newest frame's row and logit, for a flush that comes with the next call
+        if (wid == 3)
+            stream_copy_row(m.last_row + (size_t)b * m.row_bytes, s_chunk + ((size_t)b * Tc + (Tc - 1)) * m.row_bytes,
+                            m.row_bytes, lane);
+        if (nf > 0) last = pos0 + fire_list[nf - 1];
+        if (tid == 0) m.last_score[b] = srow[Tc - 1];
+    } else if (tid == 0) {
+        state_cur[b] = cur0;
+    }
+    if (cnt_out && tid == 0) cnt_out[b] = nf;
+    if (tid == 0) {
+        const int total = c0 + nf;
+        m.counts[b] = min(total, m.kmax);
+        m.dropped[b] += lost + max(total - m.kmax, 0);
+        m.state_last[b] = last;
+        state_pos[b] = pos0 + Tc;
+    }
+}
+
 // block_attn_mask rows: out[b,i,j] = (prev_fire(i) < j <= i) && valid(i)
 __global__ __launch_bounds__(256) void cif_block_mask_kernel(const int64_t* __restrict__ idx,
                                                              const int32_t* __restrict__ counts,
@@ -647,5 +780,38 @@ extern "C" int star_cif_block_mask(const int64_t* idx, const int32_t* counts, co
     hipLaunchKernelGGL(cif_block_mask_kernel, dim3(cdiv(T, 4), B), dim3(256), 0, (hipStream_t)stream, idx, counts,
                        attn_mask, lengths, T, cap, out);
     STAR_LAUNCH_CHECK("star_cif_block_mask");
+    return STAR_OK;
+}
+
+extern "C" int star_cif_stream_push(const float* score_chunk, const void* s_chunk, int dtype, const int32_t* lengths,
+                                    int B, int Tc, int d, float* state_cur, int32_t* state_pos, int32_t* state_last,
+                                    int kmax, void* mem, float* mem_scores, int64_t* mem_pos, int32_t* counts,
+                                    int32_t* dropped, void* last_row, float* last_score, int cap, int64_t* idx_out,
+                                    int32_t* cnt_out, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(lengths && state_cur && state_pos && state_last && mem && mem_scores && mem_pos && counts && dropped &&
+                     last_row && last_score,
+                 "star_cif_stream_push: null pointer");
+    STAR_REQUIRE(Tc == 0 || (score_chunk && s_chunk), "star_cif_stream_push: a chunk of %d frames without data", Tc);
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_cif_stream_push: bad dtype %d", dtype);
+    STAR_REQUIRE(B >= 1 && Tc >= 0 && Tc <= 8192 && d >= 1 && kmax >= 1, "star_cif_stream_push: bad shape B=%d Tc=%d d=%d kmax=%d",
+                 B, Tc, d, kmax);
+    STAR_REQUIRE(!idx_out || cap >= 1, "star_cif_stream_push: idx_out without cap");
+    const int row_bytes = d * (dtype == STAR_DT_BF16 ? 2 : 4);
+    STAR_REQUIRE(row_bytes % 16 == 0 && (((uintptr_t)s_chunk | (uintptr_t)mem | (uintptr_t)last_row) & 15) == 0,
+                 "star_cif_stream_push: rows must be multiples of 16 bytes at 16-byte aligned addresses (d=%d)", d);
+    const size_t smem = (size_t)2 * scan_pitch(Tc) * 4 + (size_t)(Tc > 0 ? Tc : 1) * 4;
+    if (smem > 48 * 1024) {
+        static DevOnce once;
+        if (!reserve_lds_once(once, (const void*)cif_stream_push_kernel, 112 * 1024)) {
+            set_error("star_cif_stream_push: cannot reserve LDS");
+            return STAR_ERR_LAUNCH;
+        }
+    }
+    StreamMem m = {(unsigned char*)mem, mem_scores, mem_pos, counts, dropped, (unsigned char*)last_row, last_score,
+                   state_last, kmax, row_bytes};
+    hipLaunchKernelGGL(cif_stream_push_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, score_chunk,
+                       (const unsigned char*)s_chunk, lengths, Tc, state_cur, state_pos, m, cap, idx_out, cnt_out);
+    STAR_LAUNCH_CHECK("star_cif_stream_push");
     return STAR_OK;
 }

@@ -160,10 +160,13 @@ class NuggetOpsMixin:
 def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
                       limit_cross_attn=False, scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
                       layer_idx=0, key_lengths=None, output_attentions=False, dropout_p=0.0, dropout_rng=None,
-                      kv_grad=None):
+                      kv_grad=None, query_offset=0):
     """MyGPT2Attention._attn for cross-attention (my_transformer.py:535-603); dropout_p is the probability of
     `self.attn_dropout` (my_transformer.py:595; pass 0 in eval mode), applied inside the kernels.  kv_grad: the
-    gradient slot that came with key / value from share_encoder_kv() (optional).
+    gradient slot that came with key / value from share_encoder_kv() (optional).  query_offset (not in the reference):
+    the target position of the FIRST query row -- a decoding loop that feeds one token at a time passes the token's
+    index, so that the infinite-lookback mask of my_transformer.py:566 (key j visible to row i iff j <= i + 2) is
+    evaluated at the token's true row instead of row 0.
 
     query [B,h,L,hd], key/value [B,h,K,hd]; attention_mask is the additive [B,1,1,K] encoder mask produced
     by invert_attention_mask (0 / finfo.min); scorer_logits [B,Kb<=K].  Returns (attn_output, attn_weights or
@@ -183,7 +186,7 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
         if scorer_logits.shape[2] > K:
             raise ValueError(f"shared scorer_logits cover {scorer_logits.shape[2]} keys but there are {K}")
         return ops.xattn(query, key, value, bias=scorer_logits, key_len=key_lengths,
-                         ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
+                         ilk_diag=2 + int(query_offset) if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
                          dropout_p=dropout_p, dropout_rng=dropout_rng, kv_grad=kv_grad)
     if attention_mask is not None:
         if attention_mask.shape[-1] != K or attention_mask.numel() != B * K:
@@ -200,7 +203,7 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
                 s = torch.nn.functional.pad(s, (0, K - s.shape[1]))   # the pad mask covers all K keys
             bias = bias + s
     out, probs = ops.xattn(query, key, value, bias=bias, key_len=key_lengths,
-                           ilk_diag=2 if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
+                           ilk_diag=2 + int(query_offset) if limit_cross_attn else -1, scale=scale, need_probs=output_attentions,
                            dropout_p=dropout_p, dropout_rng=dropout_rng, kv_grad=kv_grad)
     return out, probs
 
@@ -330,17 +333,20 @@ class NuggetCrossAttention(nn.Module):
         return t.view(t.shape[0], t.shape[1], self.num_heads, self.head_dim).permute(0, 2, 1, 3)
 
     def _attn(self, query, key, value, attention_mask=None, head_mask=None, scorer_logits=None,
-              limit_cross_attn=False, output_attentions=False, kv_grad=None):
+              limit_cross_attn=False, output_attentions=False, kv_grad=None, query_offset=0):
         return score_biased_attn(query, key, value, attention_mask, head_mask, scorer_logits, limit_cross_attn,
                                  self.scale_attn_weights, self.scale_attn_by_inverse_layer_idx, self.layer_idx,
                                  output_attentions=output_attentions,
-                                 dropout_p=self.attn_pdrop if self.training else 0.0, kv_grad=kv_grad)
+                                 dropout_p=self.attn_pdrop if self.training else 0.0, kv_grad=kv_grad,
+                                 query_offset=query_offset)
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, use_cache=False, output_attentions=False,
-                scorer_logits=None, limit_cross_attn=False, encoder_kv=None):
-        """encoder_kv (not in the reference): this layer's element of share_encoder_kv(); encoder_hidden_states is
-        then not projected again."""
+                scorer_logits=None, limit_cross_attn=False, encoder_kv=None, query_offset=0):
+        """encoder_kv (not in the reference): this layer's element of share_encoder_kv() (or of a
+        streaming.StreamingEncoderKV); encoder_hidden_states is then not projected again.  query_offset (not in the
+        reference): target position of the first row of hidden_states, for token-by-token decoding under
+        limit_cross_attn (score_biased_attn)."""
         if encoder_hidden_states is None and encoder_kv is None:
             raise ValueError("NuggetCrossAttention is the cross-attention module: encoder_hidden_states is required")
         query = self._split_heads(self.q_attn(hidden_states))
@@ -359,7 +365,8 @@ class NuggetCrossAttention(nn.Module):
         present = (key, value) if use_cache else None
         attn_output, attn_weights = self._attn(query, key, value, encoder_attention_mask, head_mask, scorer_logits,
                                                limit_cross_attn=bool(limit_cross_attn),
-                                               output_attentions=output_attentions, kv_grad=kv_grad)
+                                               output_attentions=output_attentions, kv_grad=kv_grad,
+                                               query_offset=query_offset)
         # merge heads: the kernel already wrote [B, L, h, hd] memory order
         b, h, l, hd = attn_output.shape
         attn_output = attn_output.permute(0, 2, 1, 3).reshape(b, l, h * hd)

@@ -468,6 +468,58 @@ def cif_fire_step(alpha_chunk, lengths, state: FireState, cap: Optional[int] = N
     return idx, counts, sg
 
 
+class StreamState:
+    """Device-resident state of the streaming segmenter for B concurrent utterances (star_cif_stream_push): integrator,
+    frames consumed, newest fire, the nugget memory [B,kmax,d] with its logits and positions, fill counts, the overflow
+    counter and the newest frame's row (for the late end-of-utterance flush)."""
+
+    def __init__(self, batch: int, dim: int, kmax: int, device, dtype=torch.bfloat16):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError(f"StreamState: unsupported dtype {dtype}")
+        self.B, self.d, self.kmax, self.dtype = int(batch), int(dim), int(kmax), dtype
+        z = lambda *sh, dt: torch.zeros(*sh, dtype=dt, device=device)
+        self.cur = z(self.B, dt=torch.float32)
+        self.pos = z(self.B, dt=torch.int32)
+        self.last = torch.full((self.B,), -1, dtype=torch.int32, device=device)
+        self.mem = z(self.B, self.kmax, self.d, dt=dtype)
+        self.mem_scores = z(self.B, self.kmax, dt=torch.float32)
+        self.mem_pos = torch.full((self.B, self.kmax), -1, dtype=torch.int64, device=device)
+        self.counts = z(self.B, dt=torch.int32)
+        self.dropped = z(self.B, dt=torch.int32)
+        self.last_row = z(self.B, self.d, dt=dtype)
+        self.last_score = z(self.B, dt=torch.float32)
+
+    def reset(self, rows=None):
+        sel = slice(None) if rows is None else rows
+        for t, v in ((self.cur, 0), (self.pos, 0), (self.last, -1), (self.counts, 0), (self.dropped, 0), (self.mem_pos, -1)):
+            t[sel] = v
+
+
+def cif_stream_push(scores_chunk, s_chunk, lengths, state: StreamState, idx_out=None, cnt_out=None):
+    """One chunk through the streaming segmenter in one launch (star_cif_stream_push): scores_chunk [B,Tc] fp32 scorer
+    logits, s_chunk [B,Tc,d] semantic states, lengths [B] int32 absolute utterance lengths (INT32_MAX while unknown).
+    scores_chunk = None (and s_chunk = None): the end-of-stream flush alone.  Updates `state` in place; no host sync,
+    nothing is allocated here (HIP-graph capturable)."""
+    _need_cuda(scores_chunk, s_chunk, lengths)
+    if lengths.dtype != torch.int32 or not lengths.is_contiguous():
+        raise TypeError("cif_stream_push: lengths must be a contiguous int32 tensor")
+    if scores_chunk is None:
+        Tc, sp, cp = 0, None, None
+    else:
+        if scores_chunk.dtype != torch.float32 or not scores_chunk.is_contiguous() or not s_chunk.is_contiguous():
+            raise TypeError("cif_stream_push: scores_chunk must be contiguous fp32 and s_chunk contiguous")
+        if s_chunk.dtype != state.dtype or s_chunk.shape != (state.B, scores_chunk.shape[1], state.d):
+            raise ValueError(f"cif_stream_push: chunk {tuple(s_chunk.shape)} {s_chunk.dtype} does not match the state "
+                             f"(B={state.B}, d={state.d}, {state.dtype})")
+        Tc, sp, cp = scores_chunk.shape[1], ptr(scores_chunk), ptr(s_chunk)
+    cap = 0 if idx_out is None else idx_out.shape[1]
+    check(lib().star_cif_stream_push(sp, cp, DT_BF16 if state.dtype == torch.bfloat16 else DT_F32, ptr(lengths), state.B, Tc,
+                                     state.d, ptr(state.cur), ptr(state.pos), ptr(state.last), state.kmax, ptr(state.mem),
+                                     ptr(state.mem_scores), ptr(state.mem_pos), ptr(state.counts), ptr(state.dropped),
+                                     ptr(state.last_row), ptr(state.last_score), cap, ptr(idx_out), ptr(cnt_out),
+                                     stream_ptr()), "star_cif_stream_push")
+
+
 def cif_block_mask(idx, counts, attn_mask=None, lengths=None, T: Optional[int] = None):
     """block_attn_mask [B,T,T] fp32 (w2v_simul.py:382-402), built on demand from the fire positions."""
     _need_cuda(idx, counts, attn_mask, lengths)
