@@ -349,6 +349,21 @@ int star_scorer_bwd_mapped(const void* x, const void* w1, const void* w1ts, cons
 int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, void* dst_t, const float* t_scale,
                              void* stream);
 
+/* ---------------------------------------------------------------- a9 / 8f-1: the cross-attention projections
+ * HF Conv1D projections around the core (c_attn / q_attn / c_proj, my_transformer.py:500-501,526: y = x W + b with W
+ * [in, out]).  star_gemm_nt_bf16: out[M,N] = a[M,K] . b[N,K]^T + bias[N] -- bf16 operands (b is the weight in
+ * [out, in] layout: star_cast_transpose_bf16 writes it from the Conv1D weight), fp32 accumulate, bias fp32 or NULL,
+ * one rounding to bf16.  N and K multiples of 64; leading dimensions in elements, multiples of 8; 16-byte aligned.
+ * Meant for wide projections (the c_attn of ALL decoder layers on the shared encoder memory: N = nl * 2d); the
+ * 256 x 256 tile leaves the chip part-filled below ~256 output tiles. */
+int star_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* bias, int64_t M, int N,
+                      int K, void* out, int64_t ldo, void* stream);
+/* Bias gradient of a projection: out[n] = sum_m x[m][n], x [M,N] (dtype, leading dimension ld), out [N] fp32, in a
+ * fixed summation order (bitwise reproducible).  N % 8 == 0.  workspace: star_colsum_workspace(M, N) bytes. */
+size_t star_colsum_workspace(int64_t M, int N);
+int star_colsum(const void* x, int dtype, int64_t M, int N, int64_t ld, float* out, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- a8 (+a11): score-biased attention core
  * Replaces MyGPT2Attention._attn for cross-attention (src/models/my_transformer.py:535-603):
  *   P = softmax(Q K^T * scale + ILK + bias[b,j]),  O = P V

@@ -76,6 +76,9 @@ SIGNATURES = {
     "star_scorer_bwd_mapped": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _I, _P, _SZ,
                                     _P, _P, C.POINTER(C.c_void_p)]),
     "star_cast_transpose_bf16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "star_gemm_nt_bf16": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P, _I64, _P]),
+    "star_colsum_workspace": (_SZ, [_I64, _I]),
+    "star_colsum": (_I, [_P, _I, _I64, _I, _I64, _P, _P, _SZ, _P]),
     "star_xattn_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P]),
     "star_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P, _P, _P, _I, _P]),
 }

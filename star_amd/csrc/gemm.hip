@@ -87,6 +87,7 @@ struct GemmParams {
     int M, N;                 // logical sizes (rows of A / rows of B)
     int kchunks;              // K / BK in total
     int splits;               // split-K factor (EPI_SLAB)
+    int gm, gn;               // XCD tile grouping (0, 0 = one row panel x all column tiles): see map_tile
     const int32_t* a_rows;    // optional row gather for A (M entries), rows >= a_rows_n clamp to entry 0
     int a_rows_n;
     // epilogue operands
@@ -98,10 +99,11 @@ struct GemmParams {
     const int32_t* live_tiles; // EPI_SCORE (optional): ascending ids of the row tiles to compute (ragged batches); the
     int n_live;               // other row tiles are skipped altogether
     float* slab;              // EPI_SLAB: [splits][M][N]
-    __bf16* out;              // EPI_ROWS: out[out_rows[m]][n]
+    __bf16* out;              // EPI_ROWS: out[out_rows[m]][n] (out_rows NULL: out[m][n], m < out_rows_n)
     int64_t ldo;
     const int32_t* out_rows;
     int out_rows_n;
+    const float* out_bias;    // EPI_ROWS (optional): added per column before the bf16 rounding
     // EPI_ROWS (optional): the last fin_blocks workgroups of the launch do the scorer backward's reductions instead of
     // a GEMM tile (the dX GEMM at 12 k rows fills 188 of 256 CUs)
     int fin_blocks;
@@ -323,10 +325,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
     // current one, so only the first tile of a workgroup pays the pipeline prologue.
     constexpr bool PERSIST = (EPI == EPI_SCORE);
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    // Grouping (non-persistent kernels with many column tiles): the tiles that an XCD runs at the same time (32, in
+    // dispatch order) form gm row panels x gn column tiles, so that BOTH operand panels are shared through that XCD's
+    // L2 -- with one row panel x all nbn column tiles (the default, right for nbn <= 8) an XCD streams the whole B
+    // operand once per row panel.
+    const int g_n = p.gn > 0 ? p.gn : nbn, g_m = p.gm > 0 ? p.gm : 1;
     auto map_tile = [&](int vb, int& mt, int& nt, int& sp) -> bool {
         const int xcd = vb & 7, local = vb >> 3;
-        const int panel = (local / nbn) * 8 + xcd;
-        nt = local % nbn;
+        const int per_blk = g_m * g_n, nblk_n = (nbn + g_n - 1) / g_n;
+        const int blk = local / per_blk, within = local - blk * per_blk;
+        const int prow = blk / nblk_n, cblk = blk - prow * nblk_n;
+        const int panel = (prow * g_m + within / g_n) * 8 + xcd;
+        nt = cblk * g_n + within % g_n;
+        if (nt >= nbn) return false;
         if constexpr (PERSIST && LIVE) {
             sp = 0;
             if (panel >= p.n_live) return false;
@@ -579,7 +590,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const int m = m0 + wrow0 + mb * 16 + (lane & 15);
-            orow_[mb] = p.out_rows[min(m, p.out_rows_n - 1)];
+            orow_[mb] = p.out_rows ? p.out_rows[min(m, p.out_rows_n - 1)] : m;
+        }
+        float ob[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wcol0 + tn * 16 + ccol;
+            ob[tn] = (p.out_bias && n < p.N) ? p.out_bias[n] : 0.f;
         }
         uint8_t* W = lds + wid * EP_WAVE_BYTES;
 #pragma unroll
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
             for (int tn = 0; tn < TN; ++tn) {
                 bf16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[tm][tn][j];
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)(acc[tm][tn][j] + ob[tn]);
                 *(bf16x4*)(W + (tn * 16 + ccol) * EP_PITCH + (tm * 16 + crow4) * 2) = o;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1138,7 +1155,10 @@ __global__ __launch_bounds__(256) void scorer_bwd_finish_kernel(FinishParams f) 
 
 static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-    int grid = (((p.live_tiles ? p.n_live : nbm * p.splits) + 7) / 8) * 8 * nbn;
+    // per XCD: its row panels in groups of gm, each group x ceil(nbn / gn) column blocks of gm * gn tiles (map_tile)
+    const int g_n = p.gn > 0 ? p.gn : nbn, g_m = p.gm > 0 ? p.gm : 1;
+    const int panels_xcd = ((p.live_tiles ? p.n_live : nbm * p.splits) + 7) / 8;
+    int grid = 8 * ((panels_xcd + g_m - 1) / g_m) * ((nbn + g_n - 1) / g_n) * g_m * g_n;
     const bool bw_staged = nbn * BN <= SCORE_BW_MAXN;      // b1 / w2 fit behind the ring (d <= 3072)
     static DevOnce once[4], live_once;
     static std::atomic<int> cus[64];
@@ -1582,6 +1602,137 @@ extern "C" int star_scorer_bwd_mapped(const void* x, const void* w1, const void*
     }
 #undef STAR_HIP
     STAR_LAUNCH_CHECK("star_scorer_bwd");
+    return STAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row a9 / SURVEY 8f item 1: the cross-attention projections (HF Conv1D: y = x W + b, my_transformer.py:500-501,526).
+// star_gemm_nt_bf16 is the 256 x 256 x 64 tile above as a plain projection GEMM: out = A . B^T + bias, bf16 in / out,
+// fp32 accumulate, the bias added before the one rounding.  With N = nl * 2d = 8192 columns (the c_attn of all decoder
+// layers in one launch) the tiles an XCD runs together are grouped 4 row panels x 8 column tiles, so both operand
+// panels are shared through its L2.
+extern "C" int star_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* bias, int64_t M,
+                                 int N, int K, void* out, int64_t ldo, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(a && b && out, "star_gemm_nt_bf16: null pointer");
+    STAR_REQUIRE(M >= 1 && M < (1ll << 31) - BM && N >= 64 && N % 64 == 0 && K >= 64 && K % 64 == 0,
+                 "star_gemm_nt_bf16: bad shape M=%lld N=%d K=%d (N, K multiples of 64)", (long long)M, N, K);
+    STAR_REQUIRE(lda >= K && ldb >= K && ldo >= N && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0,
+                 "star_gemm_nt_bf16: leading dimensions must cover the rows and be multiples of 8 elements");
+    STAR_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "star_gemm_nt_bf16: operands must be 16-byte aligned");
+    GemmParams r = {};
+    r.A = (const __bf16*)a;
+    r.B = (const __bf16*)b;
+    r.lda = lda;
+    r.ldb = ldb;
+    r.M = (int)M;
+    r.N = N;
+    r.kchunks = K / BK;
+    r.splits = 1;
+    r.out = (__bf16*)out;
+    r.ldo = ldo;
+    r.out_rows = nullptr;
+    r.out_rows_n = (int)M;
+    r.out_bias = bias;
+    const int nbn = (N + BN - 1) / BN;
+    if (nbn > 8) {
+        r.gn = 8;
+        r.gm = 4;
+    }
+    if (int rc = launch_gemm(EPI_ROWS, r, (hipStream_t)stream)) return rc;
+    STAR_LAUNCH_CHECK("star_gemm_nt_bf16");
+    return STAR_OK;
+}
+
+// Bias gradient of a projection: out[n] = sum_m x[m][n] (fp32, fixed summation order: rows of a 128-row chunk by 8
+// interleaved lanes, the lanes in order, then the chunks in order -- bitwise reproducible).
+namespace star {
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Pack {
+    T v[N];
+};
+constexpr int CS_ROWS = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                          float* __restrict__ part) {
+    __shared__ float sm[8][256 + 8];
+    const int tid = threadIdx.x, cg = tid & 31, rl = tid >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int cc = min(c0, N - 8);                       // columns past N re-read valid ones; dropped at the store
+    typedef Pack<T, 8> vec8;
+    vec8 v[CS_ROWS / 8];
+#pragma unroll
+    for (int i = 0; i < CS_ROWS / 8; ++i) {
+        const int64_t r = min(r0 + rl + 8 * i, M - 1);   // every load unconditional; rows past M are dropped below
+        v[i] = *(const vec8*)(x + r * ld + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < CS_ROWS / 8; ++i) {
+        const bool ok = r0 + rl + 8 * i < M;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += ok ? (float)v[i].v[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[rl][cg * 8 + k] = acc[k];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + tid;
+    if (c < N) {
+        float t = sm[0][tid];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sm[q][tid];
+        part[(int64_t)blockIdx.y * N + c] = t;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nchunk, int N,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    int q = 0;
+    for (; q + 3 < nchunk; q += 4) {                      // four loads in flight, the order of the adds stays fixed
+        const float a0 = part[(int64_t)q * N + c], a1 = part[(int64_t)(q + 1) * N + c];
+        const float a2 = part[(int64_t)(q + 2) * N + c], a3 = part[(int64_t)(q + 3) * N + c];
+        t += a0;
+        t += a1;
+        t += a2;
+        t += a3;
+    }
+    for (; q < nchunk; ++q) t += part[(int64_t)q * N + c];
+    out[c] = t;
+}
+}  // namespace star
+
+extern "C" size_t star_colsum_workspace(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)((M + star::CS_ROWS - 1) / star::CS_ROWS) * (size_t)N * sizeof(float);
+}
+
+extern "C" int star_colsum(const void* x, int dtype, int64_t M, int N, int64_t ld, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(x && out && workspace, "star_colsum: null pointer");
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_colsum: bad dtype %d", dtype);
+    STAR_REQUIRE(M >= 1 && N >= 8 && N % 8 == 0 && ld >= N && ld % 8 == 0, "star_colsum: bad shape M=%lld N=%d ld=%lld",
+                 (long long)M, N, (long long)ld);
+    STAR_REQUIRE(((uintptr_t)x & (dtype == STAR_DT_BF16 ? 15 : 31)) == 0, "star_colsum: x must be aligned to 8 elements");
+    const int64_t nchunk = (M + CS_ROWS - 1) / CS_ROWS;
+    STAR_REQUIRE(nchunk <= 65535, "star_colsum: M=%lld too large", (long long)M);
+    if (workspace_bytes < star_colsum_workspace(M, N)) {
+        set_error("star_colsum: workspace %zu < %zu bytes", workspace_bytes, star_colsum_workspace(M, N));
+        return STAR_ERR_WORKSPACE;
+    }
+    const dim3 grid(cdiv(N, 256), (unsigned)nchunk);
+    if (dtype == STAR_DT_BF16)
+        hipLaunchKernelGGL(colsum_part_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ld, M, N,
+                           (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, M, N,
+                           (float*)workspace);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (int)nchunk, N, out);
+    STAR_LAUNCH_CHECK("star_colsum");
     return STAR_OK;
 }
 

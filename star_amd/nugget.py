@@ -251,12 +251,50 @@ def share_encoder_kv(attn_modules, encoder_hidden_states):
     if not mods:
         raise ValueError("share_encoder_kv: no attention modules")
     dt = encoder_hidden_states.dtype
-    w_all = torch.cat([m.c_attn.weight for m in mods], dim=1).to(dt)
-    b_all = torch.cat([m.c_attn.bias for m in mods], dim=0).to(dt)
     heads = {m.num_heads for m in mods}
     if len(heads) != 1:
         raise ValueError("share_encoder_kv: the layers must have the same number of heads")
-    return [EncoderKV(k, v, slot) for k, v, slot in ops.share_kv(encoder_hidden_states, w_all, b_all, len(mods), heads.pop())]
+    h = heads.pop()
+    if encoder_hidden_states.is_cuda and dt == torch.bfloat16 and encoder_hidden_states.dim() == 3:
+        # bf16 memory on the GPU: one launch of this library's GEMM (bias in the epilogue) on the transposed weights of
+        # all layers, which are rebuilt only when a weight has changed (once per optimizer step in training, never
+        # during generation) -- no per-call concatenation
+        wt_all, b_all = _kv_weight_cache(mods, dt)
+        B, Kn, d = encoder_hidden_states.shape
+        kv = ops.shared_conv1d(encoder_hidden_states.reshape(B * Kn, d), wt_all, b_all,
+                               [m.c_attn.weight for m in mods], [m.c_attn.bias for m in mods]).view(B, Kn, -1)
+        return [EncoderKV(k, v, slot) for k, v, slot in ops.split_kv(kv, len(mods), h)]
+    w_all = torch.cat([m.c_attn.weight for m in mods], dim=1).to(dt)
+    b_all = torch.cat([m.c_attn.bias for m in mods], dim=0).to(dt)
+    return [EncoderKV(k, v, slot) for k, v, slot in ops.share_kv(encoder_hidden_states, w_all, b_all, len(mods), h)]
+
+
+_KV_WEIGHTS = {}
+
+
+def _kv_weight_cache(mods, dt):
+    """(wt_all [nl*2d, d] bf16 = the layers' c_attn weights transposed, side by side; b_all [nl*2d] fp32), rebuilt when
+    any of the parameters has changed (address or version counter)."""
+    key = tuple(id(m) for m in mods)
+    tag = tuple((m.c_attn.weight.data_ptr(), m.c_attn.weight._version, m.c_attn.bias.data_ptr(), m.c_attn.bias._version)
+                for m in mods) + (dt,)
+    ent = _KV_WEIGHTS.get(key)
+    if ent is None or ent[0] != tag:
+        with torch.no_grad():
+            # (concatenate the contiguous [in, out] weights, then ONE transposing copy: a cat of transposed views is a
+            # strided gather, 45 us against 13 + 12 at nl = 4, d = 1024)
+            wt_all = torch.cat([m.c_attn.weight.detach().to(dt) for m in mods], dim=1).t().contiguous()
+            b_all = torch.cat([m.c_attn.bias.detach().to(torch.float32) for m in mods], dim=0).contiguous()
+        ent = (tag, wt_all, b_all)
+        if len(_KV_WEIGHTS) > 64:
+            _KV_WEIGHTS.clear()
+        _KV_WEIGHTS[key] = ent
+    return ent[1], ent[2]
+
+
+def clear_kv_weight_cache():
+    """Drop the transposed c_attn weights kept by share_encoder_kv() (they are rebuilt at the next call)."""
+    _KV_WEIGHTS.clear()
 
 
 class Conv1D(nn.Module):
@@ -270,6 +308,9 @@ class Conv1D(nn.Module):
         nn.init.normal_(self.weight, std=0.02)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == self.weight.dtype:
+            # same arithmetic (hipBLASLt GEMMs through torch); the bias gradient comes from star_colsum
+            return ops.conv1d(x, self.weight, self.bias)
         size_out = x.size()[:-1] + (self.nf,)
         x = torch.addmm(self.bias, x.view(-1, x.size(-1)), self.weight)
         return x.view(size_out)

@@ -1155,12 +1155,151 @@ def split_kv(kv, n_layers: int, n_heads: int):
     return [(outs[2 * l], outs[2 * l + 1], KVGradSlot(gbuf, l)) for l in range(n_layers)]
 
 
-def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int):
+def colsum(x2d):
+    """Column sums of a [M, N] bf16 / fp32 matrix in fp32, fixed summation order (star_colsum): the bias gradient of a
+    projection."""
+    _need_cuda(x2d)
+    if x2d.dim() != 2 or x2d.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f"colsum: want a 2-D bf16 / fp32 tensor, got {tuple(x2d.shape)} {x2d.dtype}")
+    if x2d.stride(1) != 1:
+        x2d = x2d.contiguous()
+    M, N = x2d.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x2d.device)
+    wsb = lib().star_colsum_workspace(M, N)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x2d.device)
+    check(lib().star_colsum(ptr(x2d), DT_BF16 if x2d.dtype == torch.bfloat16 else DT_F32, M, N, x2d.stride(0), ptr(out),
+                            ptr(ws), wsb, stream_ptr()), "star_colsum")
+    return out
+
+
+def gemm_nt_bf16(a2d, wt, bias=None):
+    """out[M,N] = a2d[M,K] @ wt[N,K]^T + bias[N] on this library's 256 x 256 MFMA tile (star_gemm_nt_bf16)."""
+    _need_cuda(a2d, wt, bias)
+    if a2d.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16:
+        raise TypeError("gemm_nt_bf16: bf16 operands only")
+    if a2d.stride(1) != 1:
+        a2d = a2d.contiguous()
+    if wt.stride(1) != 1:
+        wt = wt.contiguous()
+    M, K = a2d.shape
+    N = wt.shape[0]
+    if wt.shape[1] != K:
+        raise ValueError(f"gemm_nt_bf16: a {tuple(a2d.shape)} x wt {tuple(wt.shape)}^T")
+    bf = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a2d.device)
+    check(lib().star_gemm_nt_bf16(ptr(a2d), a2d.stride(0), ptr(wt), wt.stride(0), ptr(bf), M, N, K, ptr(out), N,
+                                  stream_ptr()), "star_gemm_nt_bf16")
+    return out
+
+
+def _own_gemm_fits(M: int, N: int, K: int, dtype) -> bool:
+    """The 256 x 256 tile fills the chip from ~256 output tiles on (MI355X: 256 CUs); below that hipBLASLt's smaller
+    tiles win."""
+    return dtype == torch.bfloat16 and N % 64 == 0 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 192
+
+
+class _Conv1D(torch.autograd.Function):
+    """HF Conv1D (y = x @ W + b, W [in, out]; the projections around the core, my_transformer.py:500-501,526).
+    Forward: this library's GEMM with the bias in its epilogue when the output has enough 256 x 256 tiles to fill the
+    chip (given wt = W^T in [out, in] layout), else torch.addmm (hipBLASLt).  Backward: two GEMMs through torch, the
+    bias gradient by star_colsum (torch's column reduction of a [4096, 1024] bf16 gradient takes 19-22 us, this 5)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wt):
+        ctx.set_materialize_grads(False)
+        x2 = x.reshape(-1, x.shape[-1])
+        M, K = x2.shape
+        N = weight.shape[1]
+        if wt is not None and x2.is_cuda and _own_gemm_fits(M, N, K, x2.dtype):
+            y = gemm_nt_bf16(x2, wt, bias)
+        else:
+            y = torch.addmm(bias.to(x2.dtype), x2, weight.to(x2.dtype))
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        ctx.b_dtype = bias.dtype
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        x2, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if g2.stride(1) != 1 or g2.stride(0) != g2.shape[1]:
+            g2 = g2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g2, weight.to(g2.dtype).t()).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(x2.t(), g2).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            if g2.is_cuda and g2.dtype in (torch.bfloat16, torch.float32) and g2.shape[1] % 8 == 0:
+                db = colsum(g2).to(ctx.b_dtype)
+            else:
+                db = g2.sum(0).to(ctx.b_dtype)
+        return dx, dw, db, None
+
+
+class _SharedConv1D(torch.autograd.Function):
+    """The c_attn projections of nl decoder layers on one input (the encoder memory) as ONE GEMM, without the
+    per-step concatenation of the layers' weights: forward out = x @ wt_all^T + b_all on this library's GEMM (wt_all
+    [nl*2d, d] = the weights transposed side by side, kept by the caller while the weights do not change); backward
+    dx = g @ wt_all (no transpose needed: wt_all IS the [K, N] operand), dW_all = x^T @ g handed back to every layer's
+    weight as a column slice, the bias gradients by star_colsum."""
+
+    @staticmethod
+    def forward(ctx, x2, wt_all, b_all, n_each, *params):
+        ctx.set_materialize_grads(False)
+        M, K = x2.shape
+        N = wt_all.shape[0]
+        if _own_gemm_fits(M, N, K, x2.dtype):
+            y = gemm_nt_bf16(x2, wt_all, b_all)
+        else:
+            y = torch.addmm(b_all.to(x2.dtype), x2, wt_all.t())
+        ctx.save_for_backward(x2, wt_all)
+        ctx.n_each = n_each
+        ctx.p_dtypes = [p.dtype for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = len(ctx.p_dtypes) // 2
+        if g is None:
+            return (None,) * (4 + 2 * nl)
+        x2, wt_all = ctx.saved_tensors
+        g2 = g if (g.stride(1) == 1 and g.stride(0) == g.shape[1]) else g.contiguous()
+        dx = torch.mm(g2, wt_all) if ctx.needs_input_grad[0] else None
+        dws = dbs = [None] * nl
+        if any(ctx.needs_input_grad[4:4 + nl]):
+            dw_all = torch.mm(x2.t(), g2)
+            dws = [dw_all[:, l * ctx.n_each:(l + 1) * ctx.n_each].to(ctx.p_dtypes[l]) for l in range(nl)]
+        if any(ctx.needs_input_grad[4 + nl:]):
+            db_all = colsum(g2)
+            dbs = [db_all[l * ctx.n_each:(l + 1) * ctx.n_each].to(ctx.p_dtypes[nl + l]) for l in range(nl)]
+        return (dx, None, None, None, *dws, *dbs)
+
+
+def shared_conv1d(x2, wt_all, b_all, weights, biases):
+    """x2 [M, d] bf16 -> [M, nl * n_each]: see _SharedConv1D.  weights / biases: the layers' Conv1D parameters (the
+    gradients go to them); wt_all / b_all: their transposed / concatenated copies."""
+    _need_cuda(x2, wt_all, b_all)
+    n_each = weights[0].shape[1]
+    return _SharedConv1D.apply(x2, wt_all, b_all, n_each, *weights, *biases)
+
+
+def conv1d(x, weight, bias, wt=None):
+    """y = x @ weight + bias for an HF Conv1D (weight [in, out]); wt: optional bf16 copy of weight^T ([out, in]) that
+    lets wide projections run on star_gemm_nt_bf16."""
+    return _Conv1D.apply(x, weight, bias, wt)
+
+
+def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int, wt_all=None):
     """K / V of n_layers cross-attention layers from ONE projection of the encoder memory.
 
     mem [B, Kn, d]; w_all [d, n_layers*2*d] = the layers' c_attn weights (HF Conv1D layout [in, out]) side by side,
-    b_all [n_layers*2*d].  One GEMM forward; backward dmem = dKV W^T and dW = mem^T dKV over all layers at once.
-    Returns split_kv() of the projection output."""
+    b_all [n_layers*2*d]; wt_all (optional, bf16 [n_layers*2*d, d]) = w_all^T, which puts the forward on
+    star_gemm_nt_bf16 with the bias in its epilogue.  One GEMM forward; backward dmem = dKV W^T and dW = mem^T dKV over
+    all layers at once, the bias gradient by star_colsum.  Returns split_kv() of the projection output."""
     if mem.dim() != 3 or w_all.dim() != 2 or w_all.shape[0] != mem.shape[2]:
         raise ValueError(f"share_kv: mem {tuple(mem.shape)} / w_all {tuple(w_all.shape)}: want [B,Kn,d] and [d, nl*2*d]")
     d = mem.shape[2]
@@ -1172,7 +1311,7 @@ def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int):
     if not (mem.dtype == w_all.dtype == b_all.dtype):
         raise TypeError("share_kv: mem, w_all and b_all must share one dtype")
     B, Kn, _ = mem.shape
-    kv = torch.addmm(b_all, mem.reshape(B * Kn, d), w_all).view(B, Kn, -1)
+    kv = conv1d(mem.reshape(B * Kn, d), w_all, b_all, wt_all).view(B, Kn, -1)
     return split_kv(kv, n_layers, n_heads)
 
 

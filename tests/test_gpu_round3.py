@@ -396,3 +396,97 @@ def test_streaming_decode_token_by_token_matches_offline_ilk(ops):
         for b in range(B):
             got = torch.stack(outs[l][b])
             assert (got - ref[b]).abs().max() <= 2e-2 * ref[b].abs().max() + 1e-3, (l, b)
+
+
+# ------------------------------------------------------------------------------------------------ f1: projections
+@pytest.mark.parametrize("M,N,K,bias", [(12000, 8192, 1024, True), (1000, 2048, 1024, True), (300, 320, 64, False),
+                                        (257, 64, 192, True), (1, 1024, 1024, True)])
+def test_projection_gemm_vs_fp32_reference(ops, M, N, K, bias):
+    """star_gemm_nt_bf16 (row a9 / 8f-1: y = x W + b of HF Conv1D, my_transformer.py:500-501,526) against the fp32
+    product of the same bf16 operands: one rounding to bf16 plus fp32 accumulation noise.  The first shape is the
+    c_attn of all four decoder layers on the configs[1] memory (the grouped XCD tile order), the others the edge cases:
+    ragged row tile, N not a multiple of the tile, a single K tile, one row."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    out = ops.gemm_nt_bf16(a, wt, b)
+    ref = a.float() @ wt.float().t()
+    if bias:
+        ref = ref + b
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    err = (out.float() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3).all(), err.max().item()
+    # strided input (a column slice of a wider matrix: the K / V halves of a c_attn output are such views)
+    wide = torch.randn(M, K + 64, generator=g).to(torch.bfloat16).to(DEV)
+    out2 = ops.gemm_nt_bf16(wide[:, 64:], wt, b)
+    ref2 = wide[:, 64:].float() @ wt.float().t() + (b if bias else 0)
+    assert ((out2.float() - ref2).abs() <= 2.0 ** -8 * ref2.abs() + 1e-3).all()
+
+
+@pytest.mark.parametrize("M,N,dtype", [(4096, 1024, torch.bfloat16), (12000, 8192, torch.bfloat16), (130, 72, torch.float32),
+                                       (1, 8, torch.bfloat16)])
+def test_colsum_bias_gradient(ops, M, N, dtype):
+    """star_colsum (the projections' bias gradient): against an fp64 column sum, and bitwise reproducible."""
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    s1, s2 = ops.colsum(x), ops.colsum(x)
+    assert torch.equal(s1, s2) and s1.dtype == torch.float32
+    ref = x.double().sum(0)
+    assert (s1.double() - ref).abs().max() <= 1e-5 * x.double().abs().sum(0).max() + 1e-6
+    xs = torch.randn(M, N + 8, generator=g).to(dtype).to(DEV)[:, 8:]              # a strided view
+    assert (ops.colsum(xs).double() - xs.double().sum(0)).abs().max() <= 1e-5 * xs.double().abs().sum(0).max() + 1e-6
+
+
+def test_conv1d_and_shared_projection_gradients(ops):
+    """ops.conv1d (torch GEMMs + star_colsum bias gradient) and ops.shared_conv1d (all layers' c_attn in one launch of
+    star_gemm_nt_bf16, no weight concatenation) against plain torch addmm autograd on the same bf16 operands."""
+    from star_amd.nugget import NuggetCrossAttention, share_encoder_kv
+    torch.manual_seed(9)
+    B, Kn, d, h, nl = 32, 375, 1024, 8, 4
+    mods = [NuggetCrossAttention(d, h, layer_idx=i).to(DEV, torch.bfloat16) for i in range(nl)]
+    mem = torch.randn(B, Kn, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    gk = [torch.randn(B, h, Kn, d // h, device=DEV).to(torch.bfloat16) * 0.1 for _ in range(2 * nl)]
+    kvs = share_encoder_kv(mods, mem)
+    outs = [t for kv in kvs for t in (kv.key, kv.value)]
+    torch.autograd.backward(outs, gk)
+    got = {"mem": mem.grad.clone(), "w": [m.c_attn.weight.grad.clone() for m in mods],
+           "b": [m.c_attn.bias.grad.clone() for m in mods], "k0": kvs[0].key.detach().clone(),
+           "v3": kvs[3].value.detach().clone()}
+    mem.grad = None
+    for m in mods:
+        m.c_attn.weight.grad = m.c_attn.bias.grad = None
+    # reference: per-layer torch addmm on the same parameters
+    ref_outs = []
+    for m in mods:
+        kv = torch.addmm(m.c_attn.bias, mem.view(-1, d), m.c_attn.weight).view(B, Kn, 2 * d)
+        k, v = kv.split(d, dim=2)
+        ref_outs += [k.view(B, Kn, h, d // h).permute(0, 2, 1, 3), v.view(B, Kn, h, d // h).permute(0, 2, 1, 3)]
+    torch.autograd.backward(ref_outs, gk)
+
+    def close(a, b, what, tol=2e-2):
+        a, b = a.float(), b.float()
+        assert (a - b).abs().max() <= tol * b.abs().max() + 1e-6, (what, (a - b).abs().max().item(), b.abs().max().item())
+    close(got["k0"], ref_outs[0], "K of layer 0", 1e-2)
+    close(got["v3"], ref_outs[7], "V of layer 3", 1e-2)
+    close(got["mem"], mem.grad, "d mem")
+    for l, m in enumerate(mods):
+        close(got["w"][l], m.c_attn.weight.grad, f"dW layer {l}")
+        close(got["b"][l], m.c_attn.bias.grad, f"db layer {l}")
+    # a weight update is seen (the transposed copies are keyed by the parameters' version counters)
+    with torch.no_grad():
+        mods[1].c_attn.weight.mul_(2.0)
+    kv2 = share_encoder_kv(mods, mem.detach())
+    close(kv2[1].key, (torch.addmm(mods[1].c_attn.bias, mem.detach().view(-1, d), mods[1].c_attn.weight)
+                       .view(B, Kn, 2 * d)[:, :, :d].view(B, Kn, h, d // h).permute(0, 2, 1, 3)), "K after an update", 1e-2)
+    # the small projections: q_attn-shaped Conv1D, gradients against torch
+    x = torch.randn(B, 128, d, device=DEV).to(torch.bfloat16).requires_grad_()
+    gy = torch.randn(B, 128, d, device=DEV).to(torch.bfloat16)
+    q = mods[0].q_attn
+    q(x).backward(gy)
+    gw, gb, gx = q.weight.grad.clone(), q.bias.grad.clone(), x.grad.clone()
+    q.weight.grad = q.bias.grad = x.grad = None
+    torch.addmm(q.bias, x.view(-1, d), q.weight).view(B, 128, d).backward(gy)
+    close(gx, x.grad, "q_attn dx", 1e-2)
+    close(gw, q.weight.grad, "q_attn dW", 1e-2)
+    close(gb, q.bias.grad, "q_attn db", 1e-2)

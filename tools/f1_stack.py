@@ -28,7 +28,7 @@ def timeit(name, fn, iters=3):
     print(f"{name:52s} {us:8.1f} us", flush=True)
     return us
 
-from star_amd.nugget import NuggetCrossAttention, share_encoder_kv, share_scorer_logits
+from star_amd.nugget import NuggetCrossAttention, clear_kv_weight_cache, share_encoder_kv, share_scorer_logits
 mods = [NuggetCrossAttention(d, h, layer_idx=i).to(dev, torch.bfloat16) for i in range(nl)]
 memg = mem.clone().requires_grad_()
 xs = [x.clone().requires_grad_() for _ in range(nl)]
@@ -36,6 +36,11 @@ gs = [torch.randn_like(x) for _ in range(nl)]
 scg = bias.clone().requires_grad_()
 
 def stack(shared):
+    # as in a training step: gradients start from None (optimizer.zero_grad(set_to_none=True)), and the weights have
+    # just been updated, so the transposed c_attn copies of share_encoder_kv() are rebuilt (once per step)
+    for t in [memg, scg] + xs + [p for m in mods for p in m.parameters()]:
+        t.grad = None
+    clear_kv_weight_cache()
     logits = share_scorer_logits(scg, nl, h)
     if shared:
         kvs = share_encoder_kv(mods, memg)
