@@ -41,7 +41,8 @@ const char* star_last_error(void);
 /* TEST-ONLY: force a kernel variant that the library would not pick on its own for the given shape, so that tests
  * and A/B timing runs reach every kernel.  Process-wide atomics, 0 = the library's own choice (the default); not
  * meant for product callers.  Returns the previous value (>= 0), or STAR_ERR_ARG for an unknown switch. */
-#define STAR_OVR_XA_BWD 0  /* attention backward: 1 = split dQ + dK/dV kernels, 2 = the fused kernel whenever legal */
+#define STAR_OVR_XA_BWD 0  /* attention backward: 1 = split dQ + dK/dV kernels, 2 = the fused kernel whenever legal,
+                            * 3 = (head dim 128) the experimental 4-wave form of the fused kernel, else as 2 */
 #define STAR_OVR_XA_DQ 1   /* 1 = the general (register-staged) dQ kernel */
 #define STAR_OVR_XA_DKV 2  /* 1 = the general dK/dV kernel */
 #define STAR_OVR_XA_NG 3   /* key groups of the register-staged attention forward / general dQ: 1 or 2 */

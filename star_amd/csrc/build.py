@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["error.cpp", "select.hip", "gather.hip", "harness.hip", "cif.hip", "cifagg.hip", "typeembed.hip", "gatherln.hip", "gemm.hip", "xattn.hip"]
+SOURCES = ["error.cpp", "select.hip", "gather.hip", "harness.hip", "cif.hip", "cifagg.hip", "typeembed.hip", "gatherln.hip", "gemm.hip", "xattn.hip", "xattn_bwd4.hip"]
 LIB = os.path.join(HERE, "libstar_nugget.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file extras (STAR_XATTN_FLAGS etc. override for experiments)
@@ -73,7 +73,8 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "star_nugget.h")]
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "xattn_drop.h"),
+            os.path.join(HERE, "..", "..", "include", "star_nugget.h"), os.path.join(HERE, "..", "..", "include", "star_harness.h")]
     jobs = []
     objs = []
     for src in SOURCES:

@@ -23,6 +23,7 @@
 // Masked logits are -inf (P and dS exactly 0), the running max starts at a finite sentinel.
 // Algorithmic FLOP per (b, layer): forward 4*L*k_b*d, backward 8*L*k_b*d (+ 4*L*k_b*d recompute).
 #include "common.h"
+#include "xattn_drop.h"
 
 namespace star {
 
@@ -92,54 +93,6 @@ __device__ __forceinline__ void tile_store(const TileRegs<HD, ROWS, NTH>& t, uin
         if (TR::TOTAL % NTH == 0 || c < TR::TOTAL) *(u32x4*)(tile + row * pitch + ch * 16) = t.v[i];
     }
 }
-
-// ---- attention-probability dropout (my_transformer.py:595): counter-based keep mask, a pure function of
-// (seed, offset, b, h, query, key) as specified in star_nugget.h, regenerated by every backward kernel
-__device__ __forceinline__ uint32_t xa_mix(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352du;
-    x ^= x >> 15;
-    x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
-}
-template <bool DROP>
-struct Drop {
-    uint32_t k1, k2, thr;
-    float inv_keep;        // 1 / (1 - p_eff)
-    int Kn;
-    __device__ __forceinline__ Drop(const star_xattn_shape& s, int b, int h) {
-        if constexpr (DROP) {
-            uint64_t seed = s.seed, off = s.offset;
-            if (s.rng_state) {
-                seed = s.rng_state[0];
-                off = s.rng_state[1];
-            }
-            const uint32_t stream = 0x9e3779b9u * (uint32_t)(b * s.h + h + 1);
-            k1 = xa_mix((uint32_t)seed ^ xa_mix((uint32_t)(seed >> 32) ^ xa_mix((uint32_t)off ^ xa_mix((uint32_t)(off >> 32) + stream))));
-            k2 = xa_mix(k1 ^ 0x85ebca6bu);
-            const double t = (double)s.dropout_p * 4294967296.0;
-            thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
-            inv_keep = (float)(1.0 / (1.0 - (double)thr * (1.0 / 4294967296.0)));
-            Kn = s.Kn;
-        }
-    }
-    __device__ __forceinline__ bool keep(int q, int key) const {
-        uint32_t x = k1 + (uint32_t)q * (uint32_t)Kn + (uint32_t)key;
-        x ^= x >> 16;
-        x *= 0x7feb352du;
-        x ^= k2;
-        x ^= x >> 15;
-        x *= 0x846ca68bu;
-        x ^= x >> 16;
-        return x >= thr;
-    }
-    // multiplier of an attention weight / of dP: 1/(1-p) where kept, 0 where dropped (1 without dropout)
-    __device__ __forceinline__ float km(int q, int key) const {
-        if constexpr (DROP) return keep(q, key) ? inv_keep : 0.f;
-        else return 1.f;
-    }
-};
 
 // ---- in-kernel time stamps (diagnostic builds only: -DSTAR_XA_STAMP; the product library has none)
 #ifdef STAR_XA_STAMP
@@ -2146,7 +2099,14 @@ static int launch_bwd_ng(const void* q, const void* k, const void* v, const void
         // only few (batch, head) pairs with MANY key rounds are left to the split pair, whose dK/dV kernel spreads
         // the key groups of one pair over several workgroups
         const int64_t bh_f = (int64_t)s->B * s->h;
-        const bool want = bwd_force ? (bwd_force == 2) : (bh_f >= 32 || s->Kn <= 512);
+        const bool want = bwd_force ? (bwd_force >= 2) : (bh_f >= 32 || s->Kn <= 512);
+        if constexpr (HD == 128) {
+            // head dim 128, test override 3 only: the 4-wave form (32 keys per wave, 32x32x16 MFMAs, half the LDS bytes
+            // per FLOP; xattn_bwd4.hip).  Measured SLOWER than the 8-wave kernel at configs[1] (55 against 43 us, cold
+            // caches): with one wave per SIMD nothing overlaps its softmax arithmetic with its MFMAs
+            if (fused_ok && bwd_force == 3)
+                return launch_bwd_fused4(DROP, q, k, v, o, do_, lse, bias, key_len, s, dq, dk, dv, dbias_part, st);
+        }
         if (fused_ok && want) {
             const int smem_f = BwdFused<HD>::BYTES;
             XA_RESERVE((xattn_bwd_fused_small_kernel<HD, DROP>), smem_f, "star_xattn_bwd");

@@ -1073,7 +1073,7 @@ def test_xattn_split_backward_path_forced(ops):
     barrier-free dK/dV) stays the path for few (batch, head) pairs with long memories.  Both are forced here through
     the test-only star_test_override() switch (same process) and compared; the general dQ / dK,dV kernels too."""
     res = {}
-    modes = {"fused": [(ops.OVR_XA_BWD, 2)], "split": [(ops.OVR_XA_BWD, 1)],
+    modes = {"fused": [(ops.OVR_XA_BWD, 2)], "fused4": [(ops.OVR_XA_BWD, 3)], "split": [(ops.OVR_XA_BWD, 1)],
              "general": [(ops.OVR_XA_DQ, 1), (ops.OVR_XA_DKV, 1)]}
     try:
         for mode, switches in modes.items():
@@ -1097,6 +1097,6 @@ def test_xattn_split_backward_path_forced(ops):
         for w in (ops.OVR_XA_BWD, ops.OVR_XA_DQ, ops.OVR_XA_DKV, ops.OVR_XA_NG):
             ops.test_override(w, 0)
     for key in res["fused"]:
-        for other in ("split", "general"):
+        for other in ("fused4", "split", "general"):
             a, b = res["fused"][key], res[other][key]
             assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max() + 1e-6, (key, other)

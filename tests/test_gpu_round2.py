@@ -156,7 +156,7 @@ def test_xattn_dropout_vs_oracle_same_mask(ops, B, h, L, K, hd, ilk, p):
     if hd in (64, 128):
         variants += [[(ops.OVR_XA_BWD, 1)], [(ops.OVR_XA_DQ, 1), (ops.OVR_XA_DKV, 1)]]
         if L <= 128:
-            variants += [[(ops.OVR_XA_BWD, 2)]]
+            variants += [[(ops.OVR_XA_BWD, 2)], [(ops.OVR_XA_BWD, 3)]]     # 8-wave fused; head dim 128: the 4-wave form
     try:
         for switches in variants:
             for w, val in switches:

@@ -43,7 +43,8 @@ for name, sw in (("fwd ring", [(ops.OVR_XA_FWD, 0)]), ("fwd register-staged", [(
     print(f"{name:24s} cold {timed(f, True):7.1f} us   warm {timed(f, False):7.1f} us  (one launch between HIP events)")
 ops.test_override(ops.OVR_XA_FWD, 0)
 o, _ = ops.xattn(q, k, v, bias=bias, key_len=kl, ilk_diag=a.ilk)
-for name, sw in (("bwd fused", [(ops.OVR_XA_BWD, 2)]), ("bwd split", [(ops.OVR_XA_BWD, 1)])):
+for name, sw in (("bwd fused (8 waves)", [(ops.OVR_XA_BWD, 2)]), ("bwd fused (4 waves)", [(ops.OVR_XA_BWD, 3)]),
+                 ("bwd split", [(ops.OVR_XA_BWD, 1)])):
     for w, val in sw:
         ops.test_override(w, val)
     f = lambda: torch.autograd.grad(o, (q, k, v, bias), go, retain_graph=True)

@@ -1,5 +1,5 @@
 """Dev tool: in-kernel timeline of an attention kernel from the -DSTAR_XA_STAMP diagnostic library
-(tools/build_stamp.sh).  usage: python tools/xa_stamps.py fwd|bwd [--B ..]"""
+(tools/build_stamp.sh).  usage: python tools/xa_stamps.py fwd|bwd|bwd4 [--B ..]   (bwd4: the experimental 4-wave fused backward)"""
 import argparse, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,6 +31,13 @@ kl = torch.full((B,), K, dtype=torch.int32, device=dev)
 junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 L_ = _lib.lib()
 L_.star_debug_read_stamps.argtypes = [ctypes.c_void_p]
+L_.star_debug_read_stamps4.argtypes = [ctypes.c_void_p]
+if a.what == "bwd4":
+    ops.test_override(ops.OVR_XA_BWD, 3)          # the experimental 4-wave fused kernel (stamps in xattn_bwd4.hip)
+    a.what = "bwd"
+    four = True
+else:
+    four = False
 buf = np.zeros(1024 * 16, dtype=np.uint64)
 for it in range(2):
     if not a.warm:
@@ -46,7 +53,7 @@ for it in range(2):
         torch.cuda.synchronize()
         torch.autograd.grad(o, (q, k, v, bias), go)
     torch.cuda.synchronize()
-    L_.star_debug_read_stamps(buf.ctypes.data)
+    (L_.star_debug_read_stamps4 if four else L_.star_debug_read_stamps)(buf.ctypes.data)
     n = min(B * h * ((L + 127) // 128), 1024)
     st = buf.reshape(1024, 16)[:n].astype(np.int64)
     t0 = st[:, 0].min()
