@@ -49,7 +49,8 @@ const char* star_last_error(void);
 #define STAR_OVR_XA_FWD 4  /* attention forward: 1 = the register-staged kernel instead of the LDS-DMA ring */
 #define STAR_OVR_SCORER_NT 5 /* scorer backward dW1 GEMM: 1 = NT on transposed copies (0 / 2: TN on the row-major
                               operands wherever a workgroup's row ids fit its LDS) */
-#define STAR_OVR_COUNT 6
+#define STAR_OVR_SCORER_FWD 6 /* scorer forward GEMM: 1 = the experimental 4-wave register-staged kernel (d >= 256) */
+#define STAR_OVR_COUNT 7
 int star_test_override(int which, int value);
 
 /* ---------------------------------------------------------------- a2 + a3: top-k anchor select

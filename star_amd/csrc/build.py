@@ -73,7 +73,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "xattn_drop.h"),
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "xattn_drop.h"), os.path.join(HERE, "gemm_nt4.h"),
             os.path.join(HERE, "..", "..", "include", "star_nugget.h"), os.path.join(HERE, "..", "..", "include", "star_harness.h")]
     jobs = []
     objs = []

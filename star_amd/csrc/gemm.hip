@@ -34,7 +34,7 @@
 
 #ifndef STAR_GEMM_ABL
 #define STAR_GEMM_ABL 0      // diagnostic builds (tools/build_abl.sh): 1 no DMA in the K loop, 2 no ds_reads, 4 no epilogue,
-                             // 8 every tile reads one of 8 cache-hot A panels; TN kernel: 1, 2, 64 no slab store (16, one
+                             // 8 every tile reads one of 8 cache-hot A panels, 32 (4-wave kernel) no staging stores; TN kernel: 1, 2, 64 no slab store (16, one
                              // ds_read_b128 in place of each pair of transposing reads, existed in the builtin version)
 #endif
 
@@ -87,6 +87,7 @@ struct GemmParams {
     int M, N;                 // logical sizes (rows of A / rows of B)
     int kchunks;              // K / BK in total
     int splits;               // split-K factor (EPI_SLAB)
+    int no4;                  // EPI_SCORE: 1 = operands of 4 GiB or more (the 4-wave kernel addresses with 32-bit offsets)
     int gm, gn;               // XCD tile grouping (0, 0 = one row panel x all column tiles): see map_tile
     const int32_t* a_rows;    // optional row gather for A (M entries), rows >= a_rows_n clamp to entry 0
     int a_rows_n;
@@ -645,6 +646,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams p) {
   }
 }
 
+}  // namespace star
+#include "gemm_nt4.h"
+namespace star {
+
 // ---------------------------------------------------------------------------------------------------------------
 // "TN" GEMM for the scorer backward: U[n][k] = sum_r G'[r][n] * X[rows[r]][k] with BOTH operands stored row-major by
 // the reduction index r (G' [Rpad][d] as the G' pass writes it, X gathered through rows[]): no G'^T, no X_sel^T pass.
@@ -1168,8 +1173,25 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
         return STAR_ERR_LAUNCH;
     }
     bool ok = true;
+    const bool four = epi == EPI_SCORE && !p.no4 && p.kchunks >= 4 && p.kchunks % 2 == 0 && p.splits == 1 &&
+                      test_override(STAR_OVR_SCORER_FWD) == 1;
+    static DevOnce once4[6];
+    void (*four_fn)(GemmParams) = nullptr;
+    if (four) {
+        const int v = (p.live_tiles ? 0 : bw_staged ? 1 : 2) * 2 + (p.relu_bits ? 1 : 0);
+        switch (v) {
+            case 0: four_fn = scorer_fwd4_kernel<false, true, false>; break;
+            case 1: four_fn = scorer_fwd4_kernel<false, true, true>; break;
+            case 2: four_fn = scorer_fwd4_kernel<true, false, false>; break;
+            case 3: four_fn = scorer_fwd4_kernel<true, false, true>; break;
+            case 4: four_fn = scorer_fwd4_kernel<false, false, false>; break;
+            default: four_fn = scorer_fwd4_kernel<false, false, true>; break;
+        }
+        ok = reserve_lds_once(once4[v], (const void*)four_fn, G4_LDS);
+    }
     switch (epi) {
         case EPI_SCORE:
+            if (four) break;
             if (p.live_tiles)
                 ok = reserve_lds_once(live_once, (const void*)gemm_nt_kernel<EPI_SCORE, false, true>, SCORE_LDS);
             else
@@ -1193,6 +1215,11 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
                 cus[dev & 63].store(n, std::memory_order_relaxed);
             }
             if (grid > n) grid = n;
+            if (four) {             // the experimental 4-wave kernel (gemm_nt4.h; measured slower): K
+                                    // stages of 32 in groups of four, at least eight
+                hipLaunchKernelGGL(four_fn, dim3(grid), dim3(G4_THREADS), G4_LDS, st, p);
+                break;
+            }
             if (p.live_tiles)      // (b1 / w2 by global loads: this form is kept for the ABI, not for speed)
                 hipLaunchKernelGGL((gemm_nt_kernel<EPI_SCORE, false, true>), dim3(grid), dim3(GEMM_THREADS), SCORE_LDS, st, p);
             else if (bw_staged)
@@ -1331,6 +1358,7 @@ static int scorer_fwd_impl(const char* who, const void* x, const void* w1, const
     p.relu_bits = (uint32_t*)relu_bits;
     p.live_tiles = live_tiles;
     p.n_live = n_live;
+    p.no4 = (N * (int64_t)d * 2 >= (1ll << 32)) || ((int64_t)d * d * 2 >= (1ll << 32));
     hipStream_t st = (hipStream_t)stream;
     if (M > 0 && (!live_tiles || n_live > 0))
         if (int rc = launch_gemm(EPI_SCORE, p, st)) return rc;

@@ -1342,4 +1342,4 @@ def test_override(which: int, value: int) -> int:
     return rc
 
 
-OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG, OVR_XA_FWD, OVR_SCORER_NT = 0, 1, 2, 3, 4, 5
+OVR_XA_BWD, OVR_XA_DQ, OVR_XA_DKV, OVR_XA_NG, OVR_XA_FWD, OVR_SCORER_NT, OVR_SCORER_FWD = 0, 1, 2, 3, 4, 5, 6

@@ -490,3 +490,38 @@ def test_conv1d_and_shared_projection_gradients(ops):
     close(gx, x.grad, "q_attn dx", 1e-2)
     close(gw, q.weight.grad, "q_attn dW", 1e-2)
     close(gb, q.bias.grad, "q_attn db", 1e-2)
+
+
+@pytest.mark.parametrize("form", ["dense", "compact", "ragged"])
+def test_scorer_forward_4wave_kernel_equals_8wave(ops, form):
+    """The experimental 4-wave register-staged scorer GEMM (gemm_nt4.h, test override STAR_OVR_SCORER_FWD = 1) against
+    the shipped 8-wave kernel: same accumulation order over k, so the ReLU sign bits -- and with them every gradient --
+    are bit-identical; the scores differ only in the order of the 256-column row sums (tolerance 1e-5 of the scale).
+    Backward through the 4-wave forward's bits is compared as well."""
+    torch.manual_seed(11)
+    B, T, d = 3, 700, 512
+    lengths = [700, 333, 0] if form != "dense" else [T] * B
+    valid = None if form == "dense" else ops.ValidFrames(lengths, T, DEV, compact=(form == "compact"))
+    x = torch.randn(B, T, d, device=DEV).bfloat16()
+    w1 = (torch.randn(d, d, device=DEV) / d ** 0.5)
+    b1, w2, b2 = torch.randn(d, device=DEV) * 0.1, torch.randn(d, device=DEV) / d ** 0.5, torch.randn(1, device=DEV)
+    gs = torch.randn(B, T, device=DEV)
+    res = []
+    try:
+        for ov in (0, 1):
+            ops.test_override(ops.OVR_SCORER_FWD, ov)
+            xs = x.clone().requires_grad_()
+            ps = [t.clone().requires_grad_() for t in (w1, b1, w2, b2)]
+            s = ops.scorer(xs, *ps, None, valid)
+            (s * gs).sum().backward()
+            res.append((s.detach(), xs.grad, [p.grad for p in ps]))
+    finally:
+        ops.test_override(ops.OVR_SCORER_FWD, 0)
+    (s8, dx8, g8), (s4, dx4, g4) = res
+    m = torch.ones(B, T, dtype=torch.bool, device=DEV) if valid is None else \
+        (torch.arange(T, device=DEV)[None, :] < torch.tensor(lengths, device=DEV)[:, None])
+    scale = s8[m].abs().max().item()
+    assert (s4[m] - s8[m]).abs().max().item() <= 1e-5 * scale
+    assert torch.equal(dx4, dx8)
+    for a, b in zip(g4, g8):
+        assert torch.equal(a, b)
