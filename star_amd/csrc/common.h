@@ -149,6 +149,49 @@ __device__ __forceinline__ float cif_serial_chain_unit(float* row, int nblk16, f
     return cur;
 }
 
+// The two-instruction chain split in two: the serial lane keeps nothing but the carry INTO every block of 16 frames
+// (carry[blk]; per 16 frames 4 ds_read_b128 and one ds_write_b32 beside the 32 dependent VALU instructions: 12.3 cycles
+// per frame, the dependent-issue floor of v_add_f32 -> v_fract_f32, against 19.1 for the loop above, whose four
+// ds_write_b128 per block take 13 cycles each on the store path -- profiles/r03_fire_chain_microbench.txt), and the
+// workgroup's threads afterwards rebuild the pre-fire integrals of all blocks at once, one block per thread, with the
+// same two instructions on the same operands: the row ends up bit-identical to cif_serial_chain_unit's.
+__device__ __forceinline__ float cif_serial_carries_unit(const float* row, float* carry, int nblk16, float cur) {
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(row + 4 * q);
+    for (int blk = 0; blk < nblk16; ++blk) {
+        f32x4 an[4];
+        const int nb = (blk + 1 < nblk16) ? blk + 1 : blk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[q] = *(const f32x4*)(row + 16 * nb + 4 * q);
+        carry[blk] = cur;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur = __builtin_amdgcn_fractf(__fadd_rn(cur, a[q][j]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = an[q];
+    }
+    return cur;
+}
+// block `blk` of the row: weights -> pre-fire integrals, from the carry into the block
+__device__ __forceinline__ void cif_expand_block_unit(float* row, const float* carry, int blk) {
+    float cur = carry[blk];
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(row + 16 * blk + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = __fadd_rn(cur, a[q][j]);
+            a[q][j] = t;
+            cur = __builtin_amdgcn_fractf(t);
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4*)(row + 16 * blk + 4 * q) = a[q];
+}
+
 // exclusive scan of one int per thread over a workgroup of NW waves (wtot: NW ints of LDS); `total` = workgroup sum
 template <int NW>
 __device__ __forceinline__ int block_excl_scan(int v, int* wtot, int& total) {

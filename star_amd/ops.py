@@ -804,30 +804,74 @@ def scorer(x, w1, b1, w2, b2, hint: Optional[ActiveRows] = None, valid: Optional
 class _DropoutState:
     """Per-device {seed, offset} pair for attention dropout, kept ON THE DEVICE so that a step captured in a HIP
     graph draws a fresh mask at every replay: every forward snapshots the pair (the backward regenerates the mask
-    from the snapshot) and advances the offset with a stream-ordered add.  Seeded from torch's CUDA generator
-    (torch.manual_seed / torch.cuda.manual_seed re-seed it)."""
-    _states = {}
+    from the snapshot) and advances the offset with a stream-ordered add.
+
+    The pair of a device is ONE tensor for the life of the process: a re-seed (torch.manual_seed /
+    torch.cuda.manual_seed with a new value, or reset_dropout_state) is written INTO it with copy_, so a graph that was
+    captured earlier sees the new seed at its next replay.  The tensor has to exist before a capture starts -- creating
+    it is an allocation plus a host-to-device copy, which a capture cannot hold: call init_dropout_state(device) (or
+    run one dropout forward) first; next() raises instead of allocating under capture.  A seed that changed cannot be
+    picked up DURING capture either (the copy_ would be recorded into the graph and replayed every time): that raises
+    too.  Ranks of a torch.distributed job draw different masks: the rank is folded into the seed."""
+    _states = {}            # device index -> [seed it was last written with, tensor]
     _forced_seed = None
+
+    @staticmethod
+    def _rank():
+        import torch.distributed as td
+        return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+    @classmethod
+    def _seed_now(cls):
+        seed = cls._forced_seed if cls._forced_seed is not None else torch.cuda.initial_seed()
+        # (splitmix-style odd multiplier: distinct ranks -> distinct 63-bit seeds, rank 0 keeps the plain seed)
+        return (seed + cls._rank() * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+
+    @classmethod
+    def state(cls, dev, restart=False):
+        seed = cls._seed_now()
+        ent = cls._states.get(dev.index)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if ent is None:
+            if capturing:
+                raise _lib.StarNuggetError(
+                    "attention dropout: the device-side {seed, offset} state of this GPU does not exist yet and cannot "
+                    "be created during HIP-graph capture; call star_amd.ops.init_dropout_state(device) before capturing")
+            ent = [seed, torch.tensor([seed, 0], dtype=torch.int64, device=dev)]
+            cls._states[dev.index] = ent
+        elif ent[0] != seed or restart:
+            if capturing:
+                raise _lib.StarNuggetError(
+                    "attention dropout: the seed changed (torch.manual_seed / reset_dropout_state) while a HIP graph is "
+                    "being captured; re-seed before the capture (replays of an existing graph pick a new seed up)")
+            ent[1].copy_(torch.tensor([seed, 0], dtype=torch.int64), non_blocking=False)
+            ent[0] = seed
+        return ent[1]
 
     @classmethod
     def next(cls, dev):
-        seed = cls._forced_seed if cls._forced_seed is not None else torch.cuda.initial_seed()
-        ent = cls._states.get(dev.index)
-        if ent is None or ent[0] != seed:
-            st = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
-            ent = (seed, st)
-            cls._states[dev.index] = ent
-        st = ent[1]
+        st = cls.state(dev)
         snap = st.clone()
         st[1:].add_(1)
         return snap
 
 
+def init_dropout_state(device=None):
+    """Create (or re-seed) the attention-dropout state of `device` now -- required once before a step that uses dropout
+    is captured in a HIP graph, harmless otherwise."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    _DropoutState.state(dev)
+
+
 def reset_dropout_state(seed: Optional[int] = None):
-    """Restart the attention-dropout stream of every device: from `seed`, or (None) from torch's CUDA seed
-    (torch.manual_seed / torch.cuda.manual_seed with a NEW value re-seed it on their own)."""
+    """Restart the attention-dropout stream of every device that has one: from `seed`, or (None) from torch's CUDA seed
+    (torch.manual_seed / torch.cuda.manual_seed with a NEW value re-seed it on their own).  The device tensors are
+    rewritten in place, so graphs captured before the call replay with the new stream."""
     _DropoutState._forced_seed = None if seed is None else int(seed)
-    _DropoutState._states.clear()
+    for idx in list(_DropoutState._states):
+        _DropoutState.state(torch.device("cuda", idx), restart=True)
 
 
 def _xattn_shape(q, k, v, o, bias_len, ilk_diag, scale, dropout=None):

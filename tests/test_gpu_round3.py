@@ -525,3 +525,62 @@ def test_scorer_forward_4wave_kernel_equals_8wave(ops, form):
     assert torch.equal(dx4, dx8)
     for a, b in zip(g4, g8):
         assert torch.equal(a, b)
+
+
+def test_dropout_state_survives_capture_and_reseed(ops):
+    """The per-device {seed, offset} tensor of attention dropout is ONE tensor for the life of the process: a graph
+    captured after init_dropout_state() draws a fresh mask at every replay, a re-seed (reset_dropout_state) is written
+    into the same tensor and is therefore seen by the replays of a graph captured BEFORE it, and a state that does not
+    exist yet cannot be created under capture (clear error instead of an illegal copy)."""
+    from star_amd import _lib
+    torch.manual_seed(5)
+    B, h, L, K, hd, p = 2, 4, 64, 96, 64, 0.3
+    q, k, v = (torch.randn(B, h, n, hd, device=DEV).bfloat16() for n in (L, K, K))
+
+    def fwd():
+        return ops.xattn(q, k, v, dropout_p=p)[0]
+
+    ops.reset_dropout_state(1001)
+    ops.init_dropout_state(DEV)
+    eager = [fwd().clone() for _ in range(3)]                      # masks 0, 1, 2 of seed 1001
+    assert not torch.equal(eager[0], eager[1])
+    ops.reset_dropout_state(1001)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        fwd()                                                       # warm-up outside the capture (offset 0 consumed)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            out = fwd()
+        # (capture does not execute: the offset is still 1)
+        for want in (eager[1], eager[2]):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
+        ops.reset_dropout_state(1001)                               # re-seed AFTER the capture, in place
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager[0])
+        ops.reset_dropout_state(2002)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert not any(torch.equal(out, e) for e in eager)
+    # a device without a state: creating one under capture is refused
+    saved = dict(ops._DropoutState._states)
+    ops._DropoutState._states.clear()
+    try:
+        with torch.cuda.stream(stream):
+            g2 = torch.cuda.CUDAGraph()
+            msg = None
+            with torch.cuda.graph(g2, stream=stream):
+                try:
+                    fwd()
+                except _lib.StarNuggetError as e:
+                    msg = str(e)
+                keep = q + 1                                        # (the capture holds one node)
+            assert msg is not None and "init_dropout_state" in msg, msg
+            del keep
+    finally:
+        ops._DropoutState._states.clear()
+        ops._DropoutState._states.update(saved)
+        ops.reset_dropout_state(None)
