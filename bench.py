@@ -63,6 +63,7 @@ def parse():
                     help="diagnostic: run the N > 1 step structure (one graph per decoder layer's attention backward) at "
                          "N = 1, to price its replay gaps; the line is marked as a custom configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the untimed clock-ramp steps in front of the warm-up")
     ap.add_argument("--no-roofline-all", action="store_true", help="skip the per-kernel-class roofline legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--decoder-grad-dtype", choices=("fp32", "bf16"), default="fp32",
@@ -393,6 +394,12 @@ def main():
             allreduce(world)
             decoder_side.join()
 
+    # Clock ramp: a fresh process starts at idle clocks, and the chip takes a few hundred steps (~0.2 s) of this load to
+    # settle -- a 20-step run measured right behind 5 warm-up steps reads 2-3 % slow.  The ramp steps are the same step,
+    # untimed, BEFORE the W warm-up steps the contract asks for; their number is reported in config.clock_ramp_steps.
+    ramp_steps = max(0, 300 - args.warmup) if not args.no_ramp else 0
+    for _ in range(ramp_steps):
+        run_step()
     for _ in range(args.warmup):
         run_step()
     sd.barrier()
@@ -529,7 +536,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": wl.get("global_batch", B * world), "frames": T,
                        "valid_frames_per_gpu": int(frames_local), "d": d, "rate": None if simul else rate,
                        "K": int(L + 2) if simul else int(inp.key_len_dev(rate)[1]), "layers": nl, "heads": h, "tgt_len": L,
-                       "parallelism": f"dp{world}", "hip_graph": graph_a is not None,
+                       "parallelism": f"dp{world}", "hip_graph": graph_a is not None, "clock_ramp_steps": ramp_steps,
                        "loss_scalar": "not formed in the timed step: the cotangents G_l of loss = sum_l <O_l, G_l> are fed "
                                       "to backward directly (one reduction kernel per layer left out; tests form the scalar)",
                        "grad_allreduce": ("2 flat buffers per step: scorer (%d fp32 values) after the step; decoder "

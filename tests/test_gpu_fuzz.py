@@ -379,6 +379,76 @@ def test_fuzz_type_embed_and_gather_layernorm(ops):
 
 
 # ------------------------------------------------------------------------------------------------ whole steps
+# ------------------------------------------------------------------------------------------------ streaming push
+def test_fuzz_stream_push(ops):
+    """star_cif_stream_push over random batches, lengths, logit scales (saturated sigmoids and exact zeros included),
+    row widths, dtypes, chunkings and end-of-utterance timings against the offline kernels: memory rows, logits,
+    positions and counts bit for bit (the offline fire scan itself is pinned to the reference's goldens elsewhere)."""
+    from tests.test_gpu_round3 import _offline_memory, _check_memory
+    for n, rng in _cases("stream"):
+        B = int(rng.integers(1, 7))
+        T = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 333, 700]))
+        dtype = torch.bfloat16 if rng.random() < 0.7 else torch.float32
+        d = int(rng.choice([8, 64, 136, 256])) if dtype == torch.bfloat16 else int(rng.choice([4, 36, 64]))
+        g = _tg(rng)
+        scores = torch.randn(B, T, generator=g) * float(rng.choice([0.5, 1.5, 6.0])) + float(rng.choice([-3.0, -1.0, 1.0]))
+        if rng.random() < 0.3:
+            scores[int(rng.integers(B))] = 25.0                       # sigmoid == 1.0 exactly: the generic chain
+        if rng.random() < 0.3 and T > 4:
+            a = int(rng.integers(0, T - 2))
+            scores[int(rng.integers(B)), a:a + int(rng.integers(1, T - a))] = -200.0      # exact zero weights
+        scores = scores.to(DEV)
+        s = torch.randn(B, T, d, generator=g).to(dtype).to(DEV)
+        lengths = [int(x) for x in rng.integers(1, T + 1, B)]
+        lengths[int(rng.integers(B))] = T
+        idx, counts, sg, mem_off = _offline_memory(ops, scores, s, lengths)
+        kmax = int(counts.max()) + int(rng.integers(0, 3))
+        ln = torch.tensor(lengths, dtype=torch.int32, device=DEV)
+        unknown = torch.full_like(ln, 2 ** 31 - 1)
+        sizes, left = [], T
+        while left:
+            c = int(min(left, rng.integers(1, max(2, int(rng.choice([4, 40, 200]))))))
+            sizes.append(c)
+            left -= c
+        mode = str(rng.choice(["known", "with_last_frame", "late"]))
+        st = ops.StreamState(B, d, max(kmax, 1), DEV, dtype)
+        off = 0
+        for c in sizes:
+            cur = ln if mode == "known" else torch.where((ln <= off + c) if mode == "with_last_frame" else (ln < off + c),
+                                                         ln, unknown)
+            ops.cif_stream_push(scores[:, off:off + c].contiguous(), s[:, off:off + c].contiguous(), cur.contiguous(), st)
+            off += c
+        if mode == "late":
+            ops.cif_stream_push(None, None, ln, st)
+        assert (st.pos == T).all()
+        _check_memory(st, idx, counts, sg, mem_off, f"stream case {n} (B{B} T{T} d{d} {dtype} {mode} {sizes[:6]})")
+
+
+# ------------------------------------------------------------------------------------------------ projections
+def test_fuzz_projection_gemm_and_colsum(ops):
+    """star_gemm_nt_bf16 (out = A . B^T + bias, one bf16 rounding) and star_colsum over random shapes, leading
+    dimensions and tile-edge cases against fp32 torch on the same bf16 operands."""
+    for n, rng in _cases("proj"):
+        M = int(rng.choice([1, 17, 255, 256, 257, 1000, 4096, 5000]))
+        N = int(rng.choice([64, 128, 192, 256, 320, 1024, 2048]))
+        K = int(rng.choice([64, 128, 256, 576, 1024]))
+        g = _tg(rng)
+        lda = K + int(rng.choice([0, 0, 64]))
+        a_full = torch.randn(M, lda, generator=g).to(torch.bfloat16).to(DEV)
+        a = a_full[:, :K]
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV) if rng.random() < 0.7 else None
+        out = ops.gemm_nt_bf16(a, b, bias)
+        ref = a.float() @ b.float().t() + (bias if bias is not None else 0.0)
+        _close(out, ref, f"proj case {n} (M{M} N{N} K{K} lda{lda} bias={bias is not None})", tol=1e-2)
+        for dt in (torch.bfloat16, torch.float32):
+            x = torch.randn(M, N, generator=g).to(dt).to(DEV)
+            cs = ops.colsum(x)
+            want = x.double().sum(0)
+            err = (cs.double() - want).abs().max().item()
+            assert err <= 1e-5 * max(x.float().abs().sum(0).max().item(), 1.0), f"colsum case {n} ({M}x{N} {dt}): {err}"
+
+
 def _step_close(a, b, what, tol=3e-2, floor=0.0):
     a, b = a.detach().float().cpu().numpy(), b.detach().numpy()
     scale = max(np.abs(b).max(), floor) + 1e-12
