@@ -512,6 +512,13 @@ def cif_stream_push(scores_chunk, s_chunk, lengths, state: StreamState, idx_out=
             raise ValueError(f"cif_stream_push: chunk {tuple(s_chunk.shape)} {s_chunk.dtype} does not match the state "
                              f"(B={state.B}, d={state.d}, {state.dtype})")
         Tc, sp, cp = scores_chunk.shape[1], ptr(scores_chunk), ptr(s_chunk)
+    if (idx_out is None) != (cnt_out is None):
+        raise ValueError("cif_stream_push: idx_out and cnt_out come together")
+    if idx_out is not None:
+        _need_cuda(idx_out, cnt_out)
+        if (idx_out.dtype != torch.int64 or idx_out.dim() != 2 or idx_out.shape[0] != state.B or not idx_out.is_contiguous()
+                or cnt_out.dtype != torch.int32 or cnt_out.shape != (state.B,) or not cnt_out.is_contiguous()):
+            raise TypeError("cif_stream_push: idx_out must be a contiguous int64 [B, cap] tensor and cnt_out int32 [B]")
     cap = 0 if idx_out is None else idx_out.shape[1]
     check(lib().star_cif_stream_push(sp, cp, DT_BF16 if state.dtype == torch.bfloat16 else DT_F32, ptr(lengths), state.B, Tc,
                                      state.d, ptr(state.cur), ptr(state.pos), ptr(state.last), state.kmax, ptr(state.mem),
