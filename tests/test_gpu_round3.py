@@ -584,3 +584,22 @@ def test_dropout_state_survives_capture_and_reseed(ops):
         ops._DropoutState._states.clear()
         ops._DropoutState._states.update(saved)
         ops.reset_dropout_state(None)
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (8, 3)])
+def test_full_size_simul_config4_shards(ops, world, rank):
+    """BASELINE.json configs[4]: ONE global batch of 512 MuST-C-shaped utterances sharded by utterance (bench.py
+    --config 4 draws it with mustc_lengths(512, 1500, 4321) and star_amd.dist.shard).  The whole simultaneous step on
+    the 512 utterances one GPU gets at N = 1, and on the 64 that rank 3 of 8 gets, through the size-independent
+    properties of the configs[2] test (resize row sums, fires ascending with the forced last fire and equal to the
+    oracle on sampled rows, exact gathers, dS only at fired frames, masked probabilities exactly 0)."""
+    import importlib.util, os
+    from star_amd import dist as sd
+    from tests.test_gpu_round2 import _simul_full_size
+    spec = importlib.util.spec_from_file_location("star_bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, tl = bench.mustc_lengths(512, 1500, 4321)
+    n, tl = sd.shard(n, rank, world), sd.shard(tl, rank, world)
+    assert len(n) == 512 // world
+    _simul_full_size(ops, len(n), 1500, n, tl, False, 40 + rank)
