@@ -219,6 +219,8 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
     __shared__ int lens[8], wtot[4], slow[8];
     const int pitch = scan_pitch(T), T16 = (T + 15) & ~15;
     float* thr_rows = fs_rows + (size_t)R * pitch;                        // [R][pitch] per-frame thresholds
+    float* carries = thr_rows + (size_t)R * pitch;                        // [R][pitch / 16] carry into every 16-frame block
+    __shared__ int unit_row[8];
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * R;
     const int nrows = min(R, B - b0);
@@ -271,22 +273,33 @@ __global__ __launch_bounds__(256) void cif_fire_scan_kernel(
         if (late) slow[r] = 1;
     }
     __syncthreads();
-    // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r
+    // phase 2: lane r of wave 0 runs the exact serial fp32 recurrence of row r.  On the common (two-instruction) path
+    // the lane keeps only the carry into every 16-frame block and all threads rebuild the pre-fire integrals afterwards
+    // (cif_serial_carries_unit / cif_expand_block_unit: 12.3 instead of 19.1 cycles per frame on the serial lane)
+    const int cpitch = pitch >> 4;
+    float c1 = 0.0f;
+    bool unit = false;
     if (tid < nrows) {
         const float c0 = state_cur ? state_cur[b0 + tid] : 0.0f;
-        const bool unit = !slow[tid] && (c0 == 0.0f || (c0 >= 1.17549435e-38f && c0 < 1.0f));
-        float c1;
+        unit = !slow[tid] && (c0 == 0.0f || (c0 >= 1.17549435e-38f && c0 < 1.0f));
+        unit_row[tid] = unit ? 1 : 0;
+        if (unit) c1 = cif_serial_carries_unit(fs_rows + tid * pitch, carries + tid * cpitch, T16 >> 4, c0);
+        else c1 = cif_serial_chain<true>(fs_rows + tid * pitch, thr_rows + tid * pitch, 1.0f, T16 >> 4, c0);
+    }
+    __syncthreads();
+    for (int r = 0; r < nrows; ++r) {
+        if (!unit_row[r]) continue;
+        for (int blk = tid; blk < (T16 >> 4); blk += 256) cif_expand_block_unit(fs_rows + r * pitch, carries + r * cpitch, blk);
+    }
+    __syncthreads();
+    if (tid < nrows) {
         if (unit) {
-            c1 = cif_serial_chain_unit(fs_rows + tid * pitch, T16 >> 4, c0);
             // the forced fire subtracts 1 whatever the integral was; every later weight of the chunk is zero
             const int n = lens[tid];
             if (n >= 1 && n <= T) c1 = __fsub_rn(fs_rows[tid * pitch + n - 1], 1.0f);
-        } else {
-            c1 = cif_serial_chain<true>(fs_rows + tid * pitch, thr_rows + tid * pitch, 1.0f, T16 >> 4, c0);
         }
         if (state_cur) state_cur[b0 + tid] = c1;
     }
-    __syncthreads();
     // phase 3 (all threads): fire_t = (I_t >= thr_t) for t < T; ascending positions by an exclusive scan over
     // contiguous chunks of frames; pad slots carry index -1 == frame T-1
     const int C = (T + 255) / 256;
@@ -698,7 +711,7 @@ extern "C" int star_cif_fire_scan(const float* alphas, const uint8_t* attn_mask,
     STAR_REQUIRE(!scores_gather || scores, "star_cif_fire_scan: scores_gather requested without scores");
     STAR_REQUIRE(T <= 16384, "star_cif_fire_scan: T=%d exceeds the 16384-frame LDS row limit", T);
     const int R = scan_rows_per_wg(B, T);
-    const size_t smem = (size_t)R * scan_pitch(T) * 8;
+    const size_t smem = (size_t)R * scan_pitch(T) * 8 + (size_t)R * (scan_pitch(T) >> 4) * 4;
     if (smem > 48 * 1024) {
         static DevOnce once;
         if (!reserve_lds_once(once, (const void*)cif_fire_scan_kernel, 152 * 1024)) {
@@ -729,7 +742,7 @@ extern "C" int star_cif_fire_step(const float* alpha_chunk, const int32_t* lengt
     STAR_REQUIRE(!scores_gather || score_chunk, "star_cif_fire_step: scores_gather requested without score_chunk");
     STAR_REQUIRE(Tc <= 16384, "star_cif_fire_step: Tc=%d exceeds the 16384-frame LDS row limit", Tc);
     const int R = scan_rows_per_wg(B, Tc);
-    const size_t smem = (size_t)R * scan_pitch(Tc) * 8;
+    const size_t smem = (size_t)R * scan_pitch(Tc) * 8 + (size_t)R * (scan_pitch(Tc) >> 4) * 4;
     if (smem > 48 * 1024) {
         static DevOnce once;
         if (!reserve_lds_once(once, (const void*)cif_fire_scan_kernel, 152 * 1024)) {
