@@ -35,21 +35,38 @@ __global__ __launch_bounds__(256) void cif_weights_kernel(const float* __restric
                                                          int64_t* __restrict__ idx_out, uint8_t* __restrict__ mask_out,
                                                          int32_t* __restrict__ counts, int32_t* __restrict__ max_count) {
     extern __shared__ __attribute__((aligned(16))) float cw_smem[];
-    __shared__ int wtot[4];
-    const int pitch = cw_pitch(T), T16 = (T + 15) & ~15;
+    __shared__ int wtot[4], slow[4];
+    const int pitch = cw_pitch(T), T16 = (T + 15) & ~15, cpitch = pitch >> 4;
     float* a_rows = cw_smem;                                  // [R][pitch] alphas
     float* i_rows = a_rows + R * pitch;                       // [R][pitch] alphas -> integral after the add
+    float* carries = i_rows + R * pitch;                      // [R][pitch / 16] carry into every 16-frame block
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * R;
     const int nrows = min(R, B - b0);
-    for (int r = 0; r < nrows; ++r)
+    if (tid < 4) slow[tid] = (threshold != 1.0f) ? 1 : 0;
+    __syncthreads();
+    for (int r = 0; r < nrows; ++r) {
+        bool odd = false;                                     // a weight outside {0} u [FLT_MIN, 1) (NaN included)
         for (int t = tid; t < T16; t += 256) {
             const float a = (t < T) ? alphas[(size_t)(b0 + r) * T + t] : 0.0f;
+            odd |= !(a == 0.0f || (a >= 1.17549435e-38f && a < 1.0f));
             a_rows[r * pitch + t] = a;
             i_rows[r * pitch + t] = a;
         }
+        if (odd) slow[r] = 1;
+    }
     __syncthreads();
-    if (tid < nrows) cif_serial_chain<false>(i_rows + tid * pitch, nullptr, threshold, T16 >> 4);
+    // threshold 1 and every weight in {0} u [FLT_MIN, 1): the two-instruction chain (common.h) with only the block
+    // carries kept by the serial lane; the integrals are rebuilt by all threads (bit-identical to the generic chain)
+    if (tid < nrows) {
+        if (!slow[tid]) cif_serial_carries_unit(i_rows + tid * pitch, carries + tid * cpitch, T16 >> 4, 0.0f);
+        else cif_serial_chain<false>(i_rows + tid * pitch, nullptr, threshold, T16 >> 4);
+    }
+    __syncthreads();
+    for (int r = 0; r < nrows; ++r) {
+        if (slow[r]) continue;
+        for (int blk = tid; blk < (T16 >> 4); blk += 256) cif_expand_block_unit(i_rows + r * pitch, carries + r * cpitch, blk);
+    }
     __syncthreads();
     const int C = (T + 255) / 256;
     for (int r = 0; r < nrows; ++r) {
@@ -248,7 +265,7 @@ extern "C" int star_cif_weights(const float* alphas, float threshold, int B, int
     }
     STAR_REQUIRE(T <= 16384, "star_cif_weights: T=%d exceeds the 16384-frame LDS row limit", T);
     const int R = cw_rows_per_wg(B, T);
-    const size_t smem = (size_t)R * cw_row_bytes(T);
+    const size_t smem = (size_t)R * cw_row_bytes(T) + (size_t)R * (cw_pitch(T) >> 4) * 4;
     STAR_REQUIRE(T < 32768, "star_cif_weights: T too large");
     if (smem > 48 * 1024) {
         static DevOnce once;
