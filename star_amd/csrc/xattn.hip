@@ -1639,8 +1639,14 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
     const int sw_row = C::swz(r16);                               // row reads: row = 16t + r16
     const int tr_row = 4 * g + (r16 >> 2);                        // transposed reads: row within a 32-row slice
     const int sw_tr = C::swz(tr_row);
-    const int sw_ds_row = (r16 & 7) << 1;                         // dS tile: 256-byte rows
-    const int sw_ds_tr = (tr_row & 7) << 1;
+    // dS tile (256-byte rows, 8-byte units = 4 queries of one key): chunk ^ (((key & 7) << 1) | ((key >> 2) & 1)), half
+    // of the chunk ^ ((key >> 3) & 1).  The 16 keys that one ds_write_b64 lane group stores then land on 16 distinct
+    // 8-byte slots of the 128-byte bank window (with the chunk swizzle alone: 4-way, 96 extra LDS cycles per wave and
+    // round), and the transposed reads of phase C still find each key's 32 bytes in one piece (conflict-free as before)
+    const int sw_ds_row = ((r16 & 7) << 1) | ((r16 >> 2) & 1);
+    const int hf_ds_row = (r16 >> 3) & 1;
+    const int sw_ds_tr = ((tr_row & 7) << 1) | ((tr_row >> 2) & 1);
+    const int hf_ds_tr = (tr_row >> 3) & 1;
     const int qw0 = wid * 16;                                     // phase C: first query of this wave
     const bool wave_has_q = qw0 < s.L;
 
@@ -1670,7 +1676,7 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(krow + ks * 32);
         }
-        uint8_t* ds_row = ds_lds + (16 * wid + r16) * DSB + 8 * (g & 1);
+        uint8_t* ds_row = ds_lds + (16 * wid + r16) * DSB + 8 * ((g & 1) ^ hf_ds_row);
 
         f32x4 dk[NT], dv[NT];
 #pragma unroll
@@ -1848,7 +1854,8 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                     const int off = trb + (((2 * nt + ((lane & 3) >> 1)) ^ sw_tr_c) << 4);
                     kt[nt] = lds_tr8(k_lds + off, k_lds + off + 16 * ROWB);
                 }
-                const int dso = (32 * kk + tr_row) * DSB + 8 * (lane & 1) + (((2 * wid + ((lane & 3) >> 1)) ^ sw_ds_tr) << 4);
+                const int dso = (32 * kk + tr_row) * DSB + 8 * ((lane & 1) ^ hf_ds_tr) +
+                                (((2 * wid + ((lane & 3) >> 1)) ^ sw_ds_tr) << 4);
                 const bf16x8 dst = lds_tr8(ds_lds + dso, ds_lds + dso + 16 * DSB);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -1885,7 +1892,9 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
                     a[j] = (__bf16)(dk[nt][j] * s.scale);
                     c[j] = (__bf16)dv[nt][j];
                 }
-                const int choff = (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) + 8 * (gv & 1);
+                // (the two 8-byte halves of a chunk trade places in rows 8-15: the 16 rows one ds_write_b64 lane group
+                // stores then fall on 16 distinct 8-byte slots instead of 8; the row reads below swap them back)
+                const int choff = (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) + 8 * ((gv & 1) ^ (r16v >> 3));
                 *(bf16x4*)(tk + r16v * ROWB + choff) = a;
                 *(bf16x4*)(tv + r16v * DSB + choff) = c;
             }
@@ -1893,8 +1902,12 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
             for (int i = 0; i < CPR / 4; ++i) {
                 const int row = lanev / CPR + i * (64 / CPR), c = lanev % CPR;
                 const int choff = (c ^ (row & (CPR - 1))) << 4;
-                const u32x4 x = *(const u32x4*)(tk + row * ROWB + choff);
-                const u32x4 y = *(const u32x4*)(tv + row * DSB + choff);
+                u32x4 x = *(const u32x4*)(tk + row * ROWB + choff);
+                u32x4 y = *(const u32x4*)(tv + row * DSB + choff);
+                if (row & 8) {
+                    x = (u32x4){x[2], x[3], x[0], x[1]};
+                    y = (u32x4){y[2], y[3], y[0], y[1]};
+                }
                 const int krow = grp * 16 + row;
                 if (krow < s.Kn) {
                     *(u32x4*)(dKb + (int64_t)krow * s.k_sr + c * 8) = x;
@@ -1915,12 +1928,14 @@ __global__ __launch_bounds__(512) void xattn_bwd_fused_small_kernel(
             bf16x4 o4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o4[j] = (__bf16)(dq[nt][j] * s.scale);
-            *(bf16x4*)(tq + r16v * ROWB + (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) + 8 * (gv & 1)) = o4;
+            *(bf16x4*)(tq + r16v * ROWB + (((2 * nt + (gv >> 1)) ^ (r16v & (CPR - 1))) << 4) +
+                       8 * ((gv & 1) ^ (r16v >> 3))) = o4;
         }
 #pragma unroll
         for (int i = 0; i < CPR / 4; ++i) {
             const int row = lanev / CPR + i * (64 / CPR), c = lanev % CPR;
-            const u32x4 x = *(const u32x4*)(tq + row * ROWB + ((c ^ (row & (CPR - 1))) << 4));
+            u32x4 x = *(const u32x4*)(tq + row * ROWB + ((c ^ (row & (CPR - 1))) << 4));
+            if (row & 8) x = (u32x4){x[2], x[3], x[0], x[1]};
             const int q = qw0 + row;
             if (q < s.L) *(u32x4*)(dQ + (int64_t)b * s.q_sb + (int64_t)h * s.q_sh + (int64_t)q * s.q_sr + c * 8) = x;
         }
