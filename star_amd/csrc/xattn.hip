@@ -1276,9 +1276,11 @@ struct DkvSmall {
     static constexpr int BYTES = 2 * QROWS * ROWB + 2 * QROWS * 4;
     static constexpr int WAVES = 8;
     // 16-byte chunk swizzle of row r: conflict-free for the b128 row reads (lane groups of the 16x16x32 A operand)
-    // and for the transposed b64 reads (8 rows x 32 B per half wave)
+    // and for the transposed b64 reads (8 rows x 32 B per half wave).  Bit 0 (HD = 128): without it the 16-byte K park
+    // stores of the fused backward -- rows r and r + 4 of an 8-lane group -- were 2-way on the 128-byte store window;
+    // the reads are conflict-free with or without it
     __device__ static __forceinline__ int swz(int r) {
-        if constexpr (HD == 128) return (r & 7) << 1;
+        if constexpr (HD == 128) return ((r & 7) << 1) | ((r >> 2) & 1);
         else return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 2) & 1);
     }
 };
