@@ -287,8 +287,10 @@ def dropout_keep_mask(seed: int, offset: int, bsz: int, heads: int, lq: int, lk:
 def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                key_mask: torch.Tensor | None, scorer_logits: torch.Tensor | None,
                limit_cross_attn: bool = False, scale: bool = True,
-               drop_mask: torch.Tensor | None = None, drop_p: float = 0.0):
-    """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch, head_mask None).
+               drop_mask: torch.Tensor | None = None, drop_p: float = 0.0,
+               head_mask: torch.Tensor | None = None):
+    """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch).  head_mask (None on
+    the reference's own call path): multiplied into the weights after the dropout (my_transformer.py:598-599).
 
     q [B,h,L,hd], k/v [B,h,K,hd], key_mask [B,K] bool (True = attend), scorer_logits [B,Kb]
     with Kb <= K (zero-extended, my_transformer.py:114-125 variant).  drop_mask [B,h,L,K] (1 = keep) with
@@ -318,6 +320,8 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     p = torch.softmax(a, dim=-1)
     if drop_mask is not None:
         p = p * drop_mask.to(p.dtype) / (1.0 - drop_p)
+    if head_mask is not None:
+        p = p * head_mask
     return p @ v, p
 
 

@@ -173,7 +173,22 @@ def score_biased_attn(query, key, value, attention_mask=None, head_mask=None, sc
     None).  The additive mask and the scorer logits are folded into one per-key bias vector, which is what the
     kernel consumes; `key_lengths` (optional, [B]) lets the kernel skip fully padded key tiles."""
     if head_mask is not None:
-        raise NotImplementedError("head_mask is always None on the reference path (get_head_mask of [None]*n_layer)")
+        # my_transformer.py:598-599: `attn_weights = attn_weights * head_mask` after the dropout.  In the form HF's
+        # get_head_mask gives a block ([1, h, 1, 1] or [B, h, 1, 1]: one factor per head) the factor commutes with
+        # P.V, so it scales the core's output (and the returned weights) per head; masks that vary over queries or
+        # keys would have to enter the kernel and are not built (the reference's own trainers pass None)
+        h = query.shape[1]
+        if head_mask.dim() != 4 or head_mask.shape[1] not in (1, h) or head_mask.shape[2:] != (1, 1) \
+                or head_mask.shape[0] not in (1, query.shape[0]):
+            raise NotImplementedError(f"head_mask {tuple(head_mask.shape)}: only per-head factors ([1 or B, 1 or h, 1, 1], "
+                                      "what get_head_mask produces) are supported")
+        out, probs = score_biased_attn(query, key, value, attention_mask, None, scorer_logits, limit_cross_attn,
+                                       scale_attn_weights, scale_attn_by_inverse_layer_idx, layer_idx, key_lengths,
+                                       output_attentions, dropout_p, dropout_rng, kv_grad, query_offset)
+        out = out * head_mask.to(out.dtype)
+        if probs is not None:
+            probs = probs * head_mask.to(probs.dtype)
+        return out, probs
     scale = 1.0
     if scale_attn_weights:
         scale = scale / (value.size(-1) ** 0.5)

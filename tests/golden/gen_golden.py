@@ -523,9 +523,35 @@ def gen_gather_ln():
              out=out, gout=gout, dhidden=hidden.grad, dweight=ln_f.weight.grad, dbias=ln_f.bias.grad)
 
 
+def gen_head_mask():
+    """MyGPT2Attention._attn (my_transformer.py:535-603) with a head mask: `attn_weights = attn_weights * head_mask`
+    after the dropout (:598-599), in the shape HF's get_head_mask hands to a block ([1, h, 1, 1], one factor per head;
+    the reference's own trainers pass None).  Pins that the factor enters after the softmax -- the returned weights,
+    the output and every gradient carry it."""
+    att = my_transformer.MyGPT2Attention
+    g = torch.Generator().manual_seed(83)
+    for name, b, h, lq, lk, hd, klen, ilk, hm in (("a", 2, 3, 5, 9, 8, [9, 6], False, [1.0, 0.0, 0.5]),
+                                                  ("ilk", 2, 4, 7, 8, 16, [8, 5], True, [0.25, 1.0, 1.0, 0.0])):
+        q = torch.randn(b, h, lq, hd, generator=g).requires_grad_()
+        k = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        v = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        sc = torch.randn(b, lk, generator=g).requires_grad_()
+        gout = torch.randn(b, h, lq, hd, generator=g)
+        head_mask = torch.tensor(hm, dtype=torch.float32).view(1, h, 1, 1).requires_grad_()
+        kmask = len_mask(klen, lk)
+        add = (1.0 - kmask[:, None, None, :].to(torch.float32)) * torch.finfo(torch.float32).min
+        me = SimpleNamespace(scale_attn_weights=True, scale_attn_by_inverse_layer_idx=False,
+                             is_cross_attention=True, layer_idx=0, attn_dropout=torch.nn.Identity())
+        o, pw = att._attn(me, q, k, v, add, head_mask, sc, limit_cross_attn=ilk)
+        (o * gout).sum().backward()
+        save("headmask_" + name, q=q, k=k, v=v, scores=sc, key_lengths=np.array(klen), ilk=np.array(ilk),
+             head_mask=head_mask, gout=gout, o=o, p=pw, dq=q.grad, dk=k.grad, dv=v.grad, dscores=sc.grad,
+             dhead_mask=head_mask.grad)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed, gen_resize_grad,
-               gen_valid_indices, gen_xattn_drop, gen_gather_ln):
+               gen_valid_indices, gen_xattn_drop, gen_gather_ln, gen_head_mask):
         if not only or fn.__name__ in only:
             fn()

@@ -603,3 +603,49 @@ def test_full_size_simul_config4_shards(ops, world, rank):
     n, tl = sd.shard(n, rank, world), sd.shard(tl, rank, world)
     assert len(n) == 512 // world
     _simul_full_size(ops, len(n), 1500, n, tl, False, 40 + rank)
+
+
+# ------------------------------------------------------------------------------------------------ head mask
+@pytest.mark.parametrize("name", ["headmask_a", "headmask_ilk"])
+def test_score_biased_attn_head_mask_golden(ops, name):
+    """my_transformer.py:598-599: `attn_weights * head_mask` after the dropout, with the [1, h, 1, 1] per-head factors
+    HF's get_head_mask hands to a block (reference run: tests/golden/gen_golden.py gen_head_mask).  The drop-in applies
+    the factor to the core's output and returned weights; output, weights and every gradient (the head mask's too)
+    against the fp32 oracle on the bf16-rounded operands (2e-2) and against the reference's own numbers (5e-2)."""
+    import os
+    from star_amd.nugget import score_biased_attn
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    q, k, v, sc, hm, gout = (torch.from_numpy(g[n]) for n in ("q", "k", "v", "scores", "head_mask", "gout"))
+    hd = q.shape[-1]
+    pad = lambda t: torch.nn.functional.pad(t, (0, 64 - hd))          # zero-padding the head dim changes nothing
+    kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
+    # the kernel scales by 1/sqrt(head dim) of what it is given (64 after the padding): the query carries the
+    # difference, c = sqrt(64 / hd), and the oracle sees exactly the query the kernel sees, divided by c again
+    c = (64 / hd) ** 0.5
+    qr = (bf16_round(q * c) / c).requires_grad_()
+    kr, vr = (bf16_round(t).requires_grad_() for t in (k, v))
+    scr, hmr = sc.clone().requires_grad_(), hm.clone().requires_grad_()
+    o_ref, p_ref = orc.xattn_core(qr, kr, vr, kmask, scr, bool(g["ilk"]), head_mask=hmr)
+    (o_ref * bf16_round(gout)).sum().backward()
+
+    qd, kd, vd = (pad(t).to(torch.bfloat16).to(DEV).requires_grad_() for t in (q * c, k, v))
+    scd, hmd = sc.to(DEV).requires_grad_(), hm.to(DEV).requires_grad_()
+    add = ((1.0 - kmask.float()) * torch.finfo(torch.float32).min).view(kmask.shape[0], 1, 1, -1).to(DEV)
+    o, p = score_biased_attn(qd, kd, vd, add, hmd, scd, limit_cross_attn=bool(g["ilk"]),
+                             output_attentions=True)
+    o.backward(pad(gout).to(torch.bfloat16).to(DEV))
+    f = lambda t: t.float().cpu()[..., :hd].numpy()
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(f(o.detach()), o_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(p.detach().float().cpu().numpy(), p_ref.detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(f(qd.grad) * c, qr.grad.numpy(), **tol)
+    np.testing.assert_allclose(f(kd.grad), kr.grad.numpy(), **tol)
+    np.testing.assert_allclose(f(vd.grad), vr.grad.numpy(), **tol)
+    np.testing.assert_allclose(scd.grad.cpu().numpy(), scr.grad.numpy(), **tol)
+    np.testing.assert_allclose(hmd.grad.cpu().numpy(), hmr.grad.numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(f(o.detach()), g["o"], rtol=5e-2, atol=5e-2)
+    # a masked head returns exact zeros, in the output and in the weights
+    dead = (hm.view(-1) == 0).nonzero().view(-1)
+    assert dead.numel() and (o.detach()[:, dead.to(DEV)] == 0).all() and (p.detach()[:, dead.to(DEV)] == 0).all()
+    with pytest.raises(NotImplementedError):
+        score_biased_attn(qd, kd, vd, add, torch.ones(1, q.shape[1], q.shape[2], 1, device=DEV), scd)

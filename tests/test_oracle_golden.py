@@ -130,6 +130,20 @@ def test_xattn(name):
     np.testing.assert_allclose(sc.grad.numpy(), g["dscores"], **tol)
 
 
+@pytest.mark.parametrize("name", ["headmask_a", "headmask_ilk"])
+def test_xattn_head_mask(name):
+    # my_transformer.py:598-599 with the [1, h, 1, 1] factors get_head_mask produces (reference run: gen_head_mask)
+    g = load(name)
+    q, k, v, sc, hm = (torch.from_numpy(g[n]).requires_grad_() for n in ("q", "k", "v", "scores", "head_mask"))
+    kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
+    o, p = orc.xattn_core(q, k, v, kmask, sc, bool(g["ilk"]), head_mask=hm)
+    (o * torch.from_numpy(g["gout"])).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    for got, want in ((o.detach(), "o"), (p.detach(), "p"), (q.grad, "dq"), (k.grad, "dk"), (v.grad, "dv"),
+                      (sc.grad, "dscores"), (hm.grad, "dhead_mask")):
+        np.testing.assert_allclose(got.numpy(), g[want], err_msg=want, **tol)
+
+
 def test_scorer():
     g = load("scorer_small")
     x, w1, b1, w2, b2 = (torch.from_numpy(g[n]).requires_grad_() for n in ("x", "w1", "b1", "w2", "b2"))
