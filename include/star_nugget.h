@@ -360,6 +360,16 @@ int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, vo
  * 256 x 256 tile leaves the chip part-filled below ~256 output tiles. */
 int star_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* bias, int64_t M, int N,
                       int K, void* out, int64_t ldo, void* stream);
+/* Weight gradients of nbatch projections of one shape in one launch (the dW = x^T g of HF Conv1D's backward, which
+ * autograd forms per layer for my_transformer.py:500-501,526): out[i * ksplit + s][m][n] = sum over the s-th of ksplit
+ * equal ranges of r of a_i[r][m] * b_i[r][n], fp32, i < nbatch.  a_i [R, M] (leading dimension lda) = the layer's
+ * input activations, b_i [R, N] (ldb) = its output gradient, both bf16 and row-major by r as they lie -- no transposed
+ * copies.  a_list / b_list: HOST arrays of nbatch device pointers.  nbatch * ksplit <= 16; R a multiple of 64 with at
+ * most 7168 rows per range; M, N >= 128, multiples of 8; 16-byte aligned operands.  The caller adds the ksplit
+ * partial products of each i.  (One such product at M = N = 1024 has 16 output tiles of 256 x 256: batching the
+ * layers is what fills the chip.) */
+int star_gemm_tn_batched_bf16(const void* const* a_list, const void* const* b_list, int nbatch, int ksplit, int64_t R,
+                              int M, int N, int64_t lda, int64_t ldb, float* out, void* stream);
 /* Bias gradient of a projection: out[n] = sum_m x[m][n], x [M,N] (dtype, leading dimension ld), out [N] fp32, in a
  * fixed summation order (bitwise reproducible).  N % 8 == 0.  workspace: star_colsum_workspace(M, N) bytes. */
 size_t star_colsum_workspace(int64_t M, int N);

@@ -7,7 +7,9 @@ inference side of the path) and `dist.py` (batch sharding + flat RCCL gradient a
 """
 from . import ops  # noqa: F401
 from .nugget import (NuggetCrossAttention, NuggetOpsMixin, NuggetScorer, gather_nuggets,  # noqa: F401
-                     gather_nuggets_layernorm, score_biased_attn, share_encoder_kv, share_scorer_logits)
+                     gather_nuggets_layernorm, score_biased_attn, share_encoder_kv, share_scorer_logits,
+                     defer_projection_weight_grads)
 
 __all__ = ["ops", "NuggetScorer", "NuggetOpsMixin", "NuggetCrossAttention", "gather_nuggets",
-           "gather_nuggets_layernorm", "score_biased_attn", "share_encoder_kv", "share_scorer_logits"]
+           "gather_nuggets_layernorm", "score_biased_attn", "share_encoder_kv", "share_scorer_logits",
+           "defer_projection_weight_grads"]

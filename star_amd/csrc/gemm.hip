@@ -80,6 +80,7 @@ struct FinishParams {
     float* db2;
 };
 
+constexpr int STAR_TN_MAX_BATCH = 16;
 struct GemmParams {
     const __bf16* A;
     const __bf16* B;
@@ -109,6 +110,11 @@ struct GemmParams {
     // a GEMM tile (the dX GEMM at 12 k rows fills 188 of 256 CUs)
     int fin_blocks;
     FinishParams fin;
+    // gemm_tn_kernel, batched form (star_gemm_tn_batched_bf16): tn_nbatch independent products of one shape, product i
+    // on operands tn_a[i] / tn_b[i], each over tn_ksplit ranges of r; "split" s = i * tn_ksplit + range.  0 = off.
+    int tn_nbatch, tn_ksplit;
+    const __bf16* tn_a[STAR_TN_MAX_BATCH];
+    const __bf16* tn_b[STAR_TN_MAX_BATCH];
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
@@ -684,15 +690,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
     if (split >= p.splits) return;
     const int m_tile = (local % tps) / nbn, n_tile = local % nbn;
     const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int cps = (p.kchunks + p.splits - 1) / p.splits;
-    const int kc0 = split * cps;
+    // batched form: split s = product s / tn_ksplit, r range s % tn_ksplit of that product's own operands
+    const __bf16* Ap = p.A;
+    const __bf16* Bp = p.B;
+    int nsp = p.splits, sp = split;
+    if (p.tn_nbatch > 0) {
+        const int bi = split / p.tn_ksplit;
+        sp = split - bi * p.tn_ksplit;
+        nsp = p.tn_ksplit;
+        // (constant indices: a run-time index into the by-value argument arrays would make hipcc copy them to scratch)
+#pragma unroll
+        for (int i = 0; i < STAR_TN_MAX_BATCH; ++i)
+            if (bi == i) {
+                Ap = p.tn_a[i];
+                Bp = p.tn_b[i];
+            }
+    }
+    const int cps = (p.kchunks + nsp - 1) / nsp;
+    const int kc0 = sp * cps;
     const int kc1 = min(p.kchunks, kc0 + cps);
     const int nk = max(0, kc1 - kc0);
 
     // row ids of this workgroup's r range (rows past the list repeat entry 0: their G' rows are zero): parked in LDS
-    // behind the ring -- after the prologue's DMA is on its way, see below
+    // behind the ring -- after the prologue's DMA is on its way, see below.  No list (batched form): row r itself.
     int* rows_lds = (int*)(lds + GEMM_LDS);
-    auto gathered = [&](int r) { return p.a_rows[r < p.a_rows_n ? r : 0]; };
+    auto gathered = [&](int r) { return p.a_rows ? p.a_rows[r < p.a_rows_n ? r : 0] : min(r, p.a_rows_n - 1); };
 
     // staging geometry: wave w stages pieces 2w, 2w+1 (4 rows x 256 B each) of every half-tile; lane l -> row
     // piece*4 + (l >> 4), LDS chunk position l & 15, source chunk = the same position with its 32-byte window XOR-ed
@@ -711,7 +733,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
         for (int i = 0; i < 2; ++i) {
             int ca = m0 + h * 128 + scol[i];
             if (ca > p.M - 8) ca = p.M - 8;
-            asrc[h][i] = p.A + ((int64_t)kc0 * BK + srow[i]) * p.lda + ca;
+            asrc[h][i] = Ap + ((int64_t)kc0 * BK + srow[i]) * p.lda + ca;
             int cb = n0 + h * 128 + scol[i];
             if (cb > p.N - 8) cb = p.N - 8;
             bcol[h][i] = cb;
@@ -737,8 +759,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_kernel(GemmParams p) {
         if ((STAR_GEMM_ABL & 1) && tn_in_loop) break;                                                        \
         if ((TT) < nk) {                                                                                     \
             uint8_t* dst_ = lds + ((TT) & 1) * BUF_BYTES + ((H) ? H_B1 : H_B0) * HALF_BYTES + wid * 2048;     \
-            glds16(p.B + (int64_t)(R0) * p.ldb + bcol[H][0], dst_);                                          \
-            glds16(p.B + (int64_t)(R1) * p.ldb + bcol[H][1], dst_ + 1024);                                   \
+            glds16(Bp + (int64_t)(R0) * p.ldb + bcol[H][0], dst_);                                           \
+            glds16(Bp + (int64_t)(R1) * p.ldb + bcol[H][1], dst_ + 1024);                                    \
         }                                                                                                    \
     } while (0)
     auto row_id = [&](int tt, int i) { return rows_lds[min(tt, nk - 1) * BK + srow[i]]; };
@@ -1239,7 +1261,7 @@ static int launch_gemm(int epi, const GemmParams& p, hipStream_t st) {
 static int launch_gemm_tn(const GemmParams& p, hipStream_t st) {
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
     const int grid = 8 * nbm * nbn * ((p.splits + 7) / 8);           // every XCD gets whole r splits
-    if (!p.a_rows || p.a_rows_n < 1) {
+    if ((!p.a_rows && p.tn_nbatch < 1) || p.a_rows_n < 1) {
         set_error("scorer GEMM (TN): the row list of x is required");
         return STAR_ERR_ARG;
     }
@@ -1669,6 +1691,50 @@ extern "C" int star_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int6
     }
     if (int rc = launch_gemm(EPI_ROWS, r, (hipStream_t)stream)) return rc;
     STAR_LAUNCH_CHECK("star_gemm_nt_bf16");
+    return STAR_OK;
+}
+
+// Weight gradients of several projections of one shape in ONE launch: out[i * ksplit + s][m][n] = sum over the s-th
+// range of r of A_i[r][m] * B_i[r][n] (fp32; i < nbatch <= 16; both operands row-major by r, as the activations x and
+// the output gradients g of an HF Conv1D lie: dW = x^T g with A = x, B = g).  One such product at M = N = 1024,
+// R = 4096 has 16 tiles of 256 x 256 -- a sixteenth of the chip, and hipBLASLt answers it with 64 x 64 tiles at
+// 0.28 PFLOP/s; eight of them, as the q_attn / c_proj layers of a 4-layer decoder produce per
+// step, fill it.  a_list / b_list are HOST arrays of nbatch device pointers (they travel in the kernel arguments).
+// The caller adds the ksplit partial products of a product up (fixed order).
+extern "C" int star_gemm_tn_batched_bf16(const void* const* a_list, const void* const* b_list, int nbatch, int ksplit,
+                                         int64_t R, int M, int N, int64_t lda, int64_t ldb, float* out, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(a_list && b_list && out, "star_gemm_tn_batched_bf16: null pointer");
+    STAR_REQUIRE(nbatch >= 1 && ksplit >= 1 && nbatch * ksplit <= STAR_TN_MAX_BATCH,
+                 "star_gemm_tn_batched_bf16: nbatch * ksplit = %d * %d exceeds %d", nbatch, ksplit, STAR_TN_MAX_BATCH);
+    STAR_REQUIRE(R >= BK && R % BK == 0 && (R / BK + ksplit - 1) / ksplit * BK <= TN_MAX_ROWS,
+                 "star_gemm_tn_batched_bf16: R = %lld must be a multiple of %d with at most %d rows per range",
+                 (long long)R, BK, TN_MAX_ROWS);
+    STAR_REQUIRE(M >= 128 && N >= 128 && M % 8 == 0 && N % 8 == 0 && lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0,
+                 "star_gemm_tn_batched_bf16: bad shape M=%d N=%d lda=%lld ldb=%lld (>= 128, multiples of 8)", M, N,
+                 (long long)lda, (long long)ldb);
+    GemmParams r = {};
+    for (int i = 0; i < nbatch; ++i) {
+        STAR_REQUIRE(a_list[i] && b_list[i] && (((uintptr_t)a_list[i] | (uintptr_t)b_list[i]) & 15) == 0,
+                     "star_gemm_tn_batched_bf16: operand %d is null or not 16-byte aligned", i);
+        r.tn_a[i] = (const __bf16*)a_list[i];
+        r.tn_b[i] = (const __bf16*)b_list[i];
+    }
+    r.A = r.tn_a[0];
+    r.B = r.tn_b[0];
+    r.lda = lda;
+    r.ldb = ldb;
+    r.M = M;
+    r.N = N;
+    r.kchunks = (int)(R / BK);
+    r.splits = nbatch * ksplit;
+    r.tn_nbatch = nbatch;
+    r.tn_ksplit = ksplit;
+    r.a_rows = nullptr;
+    r.a_rows_n = (int)R;
+    r.slab = out;
+    if (int rc = launch_gemm_tn(r, (hipStream_t)stream)) return rc;
+    STAR_LAUNCH_CHECK("star_gemm_tn_batched_bf16");
     return STAR_OK;
 }
 

@@ -312,6 +312,23 @@ def clear_kv_weight_cache():
     _KV_WEIGHTS.clear()
 
 
+def defer_projection_weight_grads(modules, enable: bool = True):
+    """Batch the weight gradients of the small projections (q_attn, c_proj of every NuggetCrossAttention found in
+    `modules`, an iterable of modules or one module) into ONE launch at the end of each backward pass
+    (ops._DeferredWeightGrads).  A training loop that calls loss.backward() sees the same
+    .grad tensors as before, up to the summation order of the fp32 accumulation; torch.autograd.grad() callers and
+    gradient hooks on these weights (hook-based DDP) must leave it off -- star_amd.dist reduces .grad after backward
+    and works with it."""
+    mods = [modules] if isinstance(modules, nn.Module) else list(modules)
+    n = 0
+    for m in mods:
+        for sub in m.modules():
+            if isinstance(sub, NuggetCrossAttention):
+                sub.q_attn.defer_weight_grad = sub.c_proj.defer_weight_grad = bool(enable)
+                n += 1
+    return n
+
+
 class Conv1D(nn.Module):
     """HF GPT-2's Conv1D (transformers 4.34 pytorch_utils.Conv1D): y = x @ weight + bias, weight [in, out]."""
 
@@ -321,11 +338,14 @@ class Conv1D(nn.Module):
         self.weight = nn.Parameter(torch.empty(nx, nf))
         self.bias = nn.Parameter(torch.zeros(nf))
         nn.init.normal_(self.weight, std=0.02)
+        # opt-in (defer_projection_weight_grads): the weight gradient is formed at the end of the backward pass, in one
+        # launch with those of the other deferred projections, and written straight to weight.grad
+        self.defer_weight_grad = False
 
     def forward(self, x):
         if x.is_cuda and x.dtype == self.weight.dtype:
             # same arithmetic (hipBLASLt GEMMs through torch); the bias gradient comes from star_colsum
-            return ops.conv1d(x, self.weight, self.bias)
+            return ops.conv1d(x, self.weight, self.bias, defer_weight_grad=self.defer_weight_grad)
         size_out = x.size()[:-1] + (self.nf,)
         x = torch.addmm(self.bias, x.view(-1, x.size(-1)), self.weight)
         return x.view(size_out)

@@ -6,6 +6,7 @@ the STAR checkout (src/models/...).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional, Sequence
 
@@ -1243,6 +1244,100 @@ def gemm_nt_bf16(a2d, wt, bias=None):
     return out
 
 
+TN_MAX_BATCH = 16            # star_gemm_tn_batched_bf16: products (times r ranges) per launch
+_TN_MAX_ROWS = 7168          # rows of one r range
+
+
+def gemm_tn_batched(a_list, b_list, ksplit: int = 1):
+    """[a_i^T @ b_i for i] in one launch of this library's TN GEMM (star_gemm_tn_batched_bf16): a_i [R, M], b_i [R, N]
+    bf16, all of one shape and row stride -> fp32 [len(a_list), M, N].  ksplit: r ranges per product (their partial
+    products are added here, in order)."""
+    nb = len(a_list)
+    if nb < 1 or len(b_list) != nb or nb * ksplit > TN_MAX_BATCH:
+        raise ValueError(f"gemm_tn_batched: {nb} products x {ksplit} ranges (at most {TN_MAX_BATCH} together)")
+    _need_cuda(*a_list, *b_list)
+    a0, b0 = a_list[0], b_list[0]
+    for a, b in zip(a_list, b_list):
+        if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.dim() != 2 or b.dim() != 2:
+            raise TypeError("gemm_tn_batched: 2-D bf16 operands only")
+        if a.shape != a0.shape or b.shape != b0.shape or a.stride() != a0.stride() or b.stride() != b0.stride() \
+                or a.shape[0] != b.shape[0] or a.stride(1) != 1 or b.stride(1) != 1 or a.device != a0.device:
+            raise ValueError("gemm_tn_batched: the products must share one shape, row stride and device")
+    R, M = a0.shape
+    N = b0.shape[1]
+    out = torch.empty((nb * ksplit, M, N), dtype=torch.float32, device=a0.device)
+    pa = (C.c_void_p * nb)(*[a.data_ptr() for a in a_list])
+    pb = (C.c_void_p * nb)(*[b.data_ptr() for b in b_list])
+    check(lib().star_gemm_tn_batched_bf16(pa, pb, nb, ksplit, R, M, N, a0.stride(0), b0.stride(0), ptr(out),
+                                          stream_ptr()), "star_gemm_tn_batched_bf16")
+    return out if ksplit == 1 else out.view(nb, ksplit, M, N).sum(1)
+
+
+def _tn_batch_fits(x2, g2) -> bool:
+    R, M = x2.shape
+    N = g2.shape[1]
+    ks = 1
+    while R // ks > _TN_MAX_ROWS and ks < TN_MAX_BATCH:
+        ks *= 2
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and g2.dtype == torch.bfloat16 and R % (64 * ks) == 0
+            and R // ks <= _TN_MAX_ROWS and M >= 128 and N >= 128 and M % 8 == 0 and N % 8 == 0
+            and x2.stride(1) == 1 and g2.stride(1) == 1 and x2.stride(0) % 8 == 0 and g2.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 0)
+
+
+class _DeferredWeightGrads:
+    """Weight gradients of the small projections (q_attn / c_proj: dW = x^T g, [d, B*L] x [B*L, d]), held back until
+    the backward pass ends and then formed together.  One of them has 16 output tiles of 256 x 256 -- hipBLASLt gives
+    it 64 x 64 tiles at 0.28 PFLOP/s, 31 us at M = 4096, d = 1024 -- while the eight of a 4-layer decoder fill the chip
+    in one launch of star_gemm_tn_batched_bf16.  Opt-in (Conv1D.defer_weight_grad / defer_projection_weight_grads):
+    the gradients are written to `.grad` by an end-of-backward callback of the autograd engine, so they do not exist
+    for torch.autograd.grad() callers and gradient hooks on the weights (hook-based DDP) do not see them."""
+
+    def __init__(self):
+        self.items = []              # (x2, g2, weight)
+        self.armed = False
+
+    def add(self, x2, g2, weight):
+        self.items.append((x2, g2, weight))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        items, self.items, self.armed = self.items, [], False
+        groups = {}
+        for x2, g2, w in items:
+            groups.setdefault((tuple(x2.shape), x2.stride(0), tuple(g2.shape), g2.stride(0), x2.device), []).append(
+                (x2, g2, w))
+        with torch.no_grad():
+            for grp in groups.values():
+                R, M = grp[0][0].shape
+                N = grp[0][1].shape[1]
+                tiles = ((M + 255) // 256) * ((N + 255) // 256)
+                # r ranges per product: as many (a power of two) as it takes to reach one workgroup per CU, within the
+                # 16 (product, range) pairs of a launch -- 8 products of 1024 x 1024: 2 ranges, 256 workgroups
+                ks = 1
+                while (tiles * min(len(grp), TN_MAX_BATCH // ks) * ks < 256 and ks < TN_MAX_BATCH
+                       and R % (128 * ks) == 0) or R // ks > _TN_MAX_ROWS:
+                    ks *= 2
+                per = max(1, TN_MAX_BATCH // ks)
+                for at in range(0, len(grp), per):
+                    part = grp[at:at + per]
+                    dws = gemm_tn_batched([x for x, _, _ in part], [g for _, g, _ in part], ks)
+                    by_dtype = {}
+                    for i, (_, _, w) in enumerate(part):
+                        if w.dtype not in by_dtype:
+                            by_dtype[w.dtype] = dws if w.dtype == torch.float32 else dws.to(w.dtype)
+                        dw = by_dtype[w.dtype][i]
+                        if w.grad is None:
+                            w.grad = dw
+                        else:
+                            w.grad.add_(dw)
+
+
+_deferred_wgrads = _DeferredWeightGrads()
+
+
 def _own_gemm_fits(M: int, N: int, K: int, dtype) -> bool:
     """The 256 x 256 tile fills the chip from ~256 output tiles on (MI355X: 256 CUs); below that hipBLASLt's smaller
     tiles win."""
@@ -1256,8 +1351,9 @@ class _Conv1D(torch.autograd.Function):
     bias gradient by star_colsum (torch's column reduction of a [4096, 1024] bf16 gradient takes 19-22 us, this 5)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, wt):
+    def forward(ctx, x, weight, bias, wt, defer_wgrad=False):
         ctx.set_materialize_grads(False)
+        ctx.defer_wgrad = bool(defer_wgrad)
         x2 = x.reshape(-1, x.shape[-1])
         M, K = x2.shape
         N = weight.shape[1]
@@ -1273,7 +1369,7 @@ class _Conv1D(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x2, weight = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         if g2.stride(1) != 1 or g2.stride(0) != g2.shape[1]:
@@ -1282,13 +1378,16 @@ class _Conv1D(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(g2, weight.to(g2.dtype).t()).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(x2.t(), g2).to(weight.dtype)
+            if ctx.defer_wgrad and weight.is_leaf and _tn_batch_fits(x2, g2):
+                _deferred_wgrads.add(x2, g2, weight)         # formed with the other layers' at the end of backward
+            else:
+                dw = torch.mm(x2.t(), g2).to(weight.dtype)
         if ctx.needs_input_grad[2]:
             if g2.is_cuda and g2.dtype in (torch.bfloat16, torch.float32) and g2.shape[1] % 8 == 0:
                 db = colsum(g2).to(ctx.b_dtype)
             else:
                 db = g2.sum(0).to(ctx.b_dtype)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _SharedConv1D(torch.autograd.Function):
@@ -1338,10 +1437,11 @@ def shared_conv1d(x2, wt_all, b_all, weights, biases):
     return _SharedConv1D.apply(x2, wt_all, b_all, n_each, *weights, *biases)
 
 
-def conv1d(x, weight, bias, wt=None):
+def conv1d(x, weight, bias, wt=None, defer_weight_grad=False):
     """y = x @ weight + bias for an HF Conv1D (weight [in, out]); wt: optional bf16 copy of weight^T ([out, in]) that
-    lets wide projections run on star_gemm_nt_bf16."""
-    return _Conv1D.apply(x, weight, bias, wt)
+    lets wide projections run on star_gemm_nt_bf16.  defer_weight_grad: see _DeferredWeightGrads (opt-in: the weight's
+    gradient is written to .grad when the backward pass ends, batched with the other deferred projections)."""
+    return _Conv1D.apply(x, weight, bias, wt, defer_weight_grad)
 
 
 def share_kv(mem, w_all, b_all, n_layers: int, n_heads: int, wt_all=None):

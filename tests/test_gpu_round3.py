@@ -649,3 +649,74 @@ def test_score_biased_attn_head_mask_golden(ops, name):
     assert dead.numel() and (o.detach()[:, dead.to(DEV)] == 0).all() and (p.detach()[:, dead.to(DEV)] == 0).all()
     with pytest.raises(NotImplementedError):
         score_biased_attn(qd, kd, vd, add, torch.ones(1, q.shape[1], q.shape[2], 1, device=DEV), scd)
+
+
+# ------------------------------------------------------------------------------------------------ batched dW (8f-1)
+@pytest.mark.parametrize("nb,ks,R,M,N,pad", [(3, 1, 256, 256, 384, 0), (8, 2, 4096, 1024, 1024, 0), (1, 4, 1024, 136, 128, 8),
+                                             (2, 8, 512, 520, 264, 16), (16, 1, 64, 128, 128, 0)])
+def test_gemm_tn_batched_vs_fp32(ops, nb, ks, R, M, N, pad):
+    """star_gemm_tn_batched_bf16 (the dW = x^T g of HF Conv1D's backward for several layers at once,
+    my_transformer.py:500-501,526) against fp64 matmuls of the same bf16 operands: fp32 accumulation, so 1e-4 of the
+    result's scale; row strides wider than the rows, ragged last tiles, every r-range count."""
+    g = torch.Generator(device=DEV).manual_seed(nb * 1000 + R)
+    xs = [torch.randn(R, M + pad, device=DEV, generator=g).bfloat16()[:, :M] for _ in range(nb)]
+    gs = [torch.randn(R, N + pad, device=DEV, generator=g).bfloat16()[:, :N] for _ in range(nb)]
+    out = ops.gemm_tn_batched(xs, gs, ks)
+    assert out.shape == (nb, M, N) and out.dtype == torch.float32
+    for i in range(nb):
+        ref = xs[i].double().t() @ gs[i].double()
+        err = (out[i].double() - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item(), (i, err)
+    with pytest.raises(ValueError):
+        ops.gemm_tn_batched(xs, gs[:-1] + [gs[-1][:, :N - 8]], ks)         # mixed shapes
+    with pytest.raises(ValueError):
+        ops.gemm_tn_batched([x[:R - 8] for x in xs], [t[:R - 8] for t in gs], ks)      # R not a multiple of 64
+
+
+def test_deferred_projection_weight_grads_equal_immediate(ops):
+    """defer_projection_weight_grads: q_attn / c_proj weight gradients formed in one launch when backward() ends
+    (ops._DeferredWeightGrads) against the per-layer torch.mm gradients of the same stack: the weights' .grad equal up
+    to the bf16 rounding of two fp32 sums taken in different orders, every other gradient bit-identical; a second
+    backward accumulates; modules that do not fit the kernel (fp32 here) keep the immediate path."""
+    from star_amd.nugget import NuggetCrossAttention, defer_projection_weight_grads
+    torch.manual_seed(3)
+    B, L, K, d, h, nl = 4, 64, 50, 256, 4, 3
+    mods = [NuggetCrossAttention(d, h, layer_idx=i).to(DEV, torch.bfloat16) for i in range(nl)]
+    mem = torch.randn(B, K, d, device=DEV).bfloat16().requires_grad_()
+    xs = [torch.randn(B, L, d, device=DEV).bfloat16().requires_grad_() for _ in range(nl)]
+    gouts = [torch.randn(B, L, d, device=DEV).bfloat16() for _ in range(nl)]
+    sc = torch.randn(B, K, device=DEV).requires_grad_()
+
+    def run(times=1):
+        for t in [mem, sc] + xs + [p for m in mods for p in m.parameters()]:
+            t.grad = None
+        for _ in range(times):
+            outs = [m(x, encoder_hidden_states=mem, scorer_logits=sc)[0] for m, x in zip(mods, xs)]
+            torch.autograd.backward(outs, gouts)
+        torch.cuda.synchronize()
+        return ({n + str(i): p.grad.clone() for i, m in enumerate(mods) for n, p in m.named_parameters()},
+                [t.grad.clone() for t in [mem, sc] + xs])
+
+    w_ref, o_ref = run()
+    assert defer_projection_weight_grads(mods) == nl
+    w_def, o_def = run()
+    w_def2, _ = run(times=2)
+    defer_projection_weight_grads(mods, False)
+    w_off, _ = run()
+    for a, b in zip(o_ref, o_def):
+        assert torch.equal(a, b)
+    for n in w_ref:
+        if "q_attn.weight" in n or "c_proj.weight" in n:
+            scale = w_ref[n].float().abs().max().item()
+            assert (w_def[n].float() - w_ref[n].float()).abs().max().item() <= 1e-2 * scale, n
+            assert (w_def2[n].float() - 2 * w_ref[n].float()).abs().max().item() <= 3e-2 * scale, n
+            assert not torch.equal(w_def[n], torch.zeros_like(w_def[n]))
+        else:
+            assert torch.equal(w_def[n], w_ref[n]), n
+        assert torch.equal(w_off[n], w_ref[n]), n
+    # fp32 modules do not fit the bf16 kernel: the flag is accepted and the gradients come the usual way
+    m32 = NuggetCrossAttention(d, h).to(DEV)
+    defer_projection_weight_grads(m32)
+    x32 = torch.randn(2, 8, d, device=DEV, requires_grad=True)
+    m32(x32.bfloat16().float(), encoder_hidden_states=mem.detach().float())[0].sum().backward()
+    assert m32.q_attn.weight.grad is not None and m32.c_proj.weight.grad is not None

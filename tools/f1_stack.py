@@ -55,3 +55,8 @@ if "--shared-only" not in sys.argv:
 if "--per-layer-only" not in sys.argv:
     tt = timeit("4 cross-attention layers fwd+bwd, share_encoder_kv", lambda: stack(True))
 print(f"decoder cross-attention stack, forward + backward: {ts:.1f} -> {tt:.1f} us")
+if "--per-layer-only" not in sys.argv:
+    from star_amd.nugget import defer_projection_weight_grads
+    defer_projection_weight_grads(mods)
+    td = timeit("  + q_attn / c_proj weight gradients in one launch", lambda: stack(True))
+    print(f"with defer_projection_weight_grads: {tt:.1f} -> {td:.1f} us")
