@@ -360,6 +360,13 @@ int star_cast_transpose_bf16(const float* src, int rows, int cols, void* dst, vo
  * 256 x 256 tile leaves the chip part-filled below ~256 output tiles. */
 int star_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* bias, int64_t M, int N,
                       int K, void* out, int64_t ldo, void* stream);
+/* dst_t[(i * cols + c)][r] = bf16(src_i[r][c]), i < n <= 16: the Conv1D weights of n layers (each [rows = in,
+ * cols = out] contiguous, fp32 or bf16 by `dtype`), transposed and laid side by side in one launch -- the [n * out, in]
+ * B operand of star_gemm_nt_bf16 for the all-layer c_attn (my_transformer.py:500-501 on the memory shared by every
+ * block, :917-928), rebuilt once per optimizer step.  src_list: HOST array of device pointers; rows, cols multiples
+ * of 64. */
+int star_transpose_list_bf16(const void* const* src_list, int n, int dtype, int rows, int cols, void* dst_t,
+                             void* stream);
 /* Weight gradients of nbatch projections of one shape in one launch (the dW = x^T g of HF Conv1D's backward, which
  * autograd forms per layer for my_transformer.py:500-501,526): out[i * ksplit + s][m][n] = sum over the s-th of ksplit
  * equal ranges of r of a_i[r][m] * b_i[r][n], fp32, i < nbatch.  a_i [R, M] (leading dimension lda) = the layer's
@@ -375,6 +382,11 @@ int star_gemm_tn_batched_bf16(const void* const* a_list, const void* const* b_li
 size_t star_colsum_workspace(int64_t M, int N);
 int star_colsum(const void* x, int dtype, int64_t M, int N, int64_t ld, float* out, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* The same for nbatch <= 16 matrices of one shape in one pair of launches (the bias gradients that go with
+ * star_gemm_tn_batched_bf16): out [nbatch][N], x_list a HOST array of device pointers, workspace nbatch *
+ * star_colsum_workspace(M, N) bytes; every out[i] is bit-identical to star_colsum of x_list[i]. */
+int star_colsum_batched(const void* const* x_list, int nbatch, int dtype, int64_t M, int N, int64_t ld, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- a8 (+a11): score-biased attention core
  * Replaces MyGPT2Attention._attn for cross-attention (src/models/my_transformer.py:535-603):

@@ -78,8 +78,10 @@ SIGNATURES = {
     "star_cast_transpose_bf16": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "star_gemm_nt_bf16": (_I, [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P, _I64, _P]),
     "star_gemm_tn_batched_bf16": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _I, _I64, _I, _I, _I64, _I64, _P, _P]),
+    "star_transpose_list_bf16": (_I, [C.POINTER(C.c_void_p), _I, _I, _I, _I, _P, _P]),
     "star_colsum_workspace": (_SZ, [_I64, _I]),
     "star_colsum": (_I, [_P, _I, _I64, _I, _I64, _P, _P, _SZ, _P]),
+    "star_colsum_batched": (_I, [C.POINTER(C.c_void_p), _I, _I, _I64, _I, _I64, _P, _P, _SZ, _P]),
     "star_xattn_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P]),
     "star_xattn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(XAttnShape), _P, _P, _P, _P, _P, _P, _I, _P]),
 }

@@ -1747,8 +1747,8 @@ struct alignas(sizeof(T) * N) Pack {
 };
 constexpr int CS_ROWS = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int N,
-                                                          float* __restrict__ part) {
+__device__ __forceinline__ void colsum_part_body(const T* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                 float* __restrict__ part) {
     __shared__ float sm[8][256 + 8];
     const int tid = threadIdx.x, cg = tid & 31, rl = tid >> 5;
     const int c0 = blockIdx.x * 256 + cg * 8;
@@ -1779,10 +1779,33 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ 
         part[(int64_t)blockIdx.y * N + c] = t;
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                          float* __restrict__ part) {
+    colsum_part_body<T>(x, ld, M, N, part);
+}
+// batched form (star_colsum_batched): matrix blockIdx.z of a list that travels in the kernel arguments
+constexpr int CS_MAX_BATCH = 16;
+struct ColsumList {
+    const void* x[CS_MAX_BATCH];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_batched_kernel(ColsumList l, int64_t ld, int64_t M, int N,
+                                                                  float* __restrict__ part) {
+    const int bi = blockIdx.z;
+    const T* x = (const T*)l.x[0];
+#pragma unroll
+    for (int i = 1; i < CS_MAX_BATCH; ++i)          // constant indices: no copy of the argument array to scratch
+        if (bi == i) x = (const T*)l.x[i];
+    colsum_part_body<T>(x, ld, M, N, part + (int64_t)bi * gridDim.y * N);
+}
+// (blockIdx.y: matrix of a batch; part / out advance by nchunk * N / N per matrix)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nchunk, int N,
                                                             float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
+    part += (int64_t)blockIdx.y * nchunk * N;
+    out += (int64_t)blockIdx.y * N;
     float t = 0.f;
     int q = 0;
     for (; q + 3 < nchunk; q += 4) {                      // four loads in flight, the order of the adds stays fixed
@@ -1795,6 +1818,31 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     }
     for (; q < nchunk; ++q) t += part[(int64_t)q * N + c];
     out[c] = t;
+}
+
+// dst_t[(z * cols + c)][r] = bf16(src_z[r][c]): the Conv1D weights of several layers ([in, out] each, fp32 or bf16),
+// transposed and laid side by side as the B operand of star_gemm_nt_bf16 (rows % 64 == 0, cols % 64 == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_list_kernel(ColsumList l, int rows, int cols, __bf16* __restrict__ dst_t) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64 * TP_PITCH];
+    const int bi = blockIdx.z;
+    const T* src = (const T*)l.x[0];
+#pragma unroll
+    for (int i = 1; i < CS_MAX_BATCH; ++i)
+        if (bi == i) src = (const T*)l.x[i];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x, c = t & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rr = (t >> 3) + pass * 32;
+        const Pack<T, 8> a = *(const Pack<T, 8>*)(src + (int64_t)(r0 + rr) * cols + c0 + c * 8);
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (__bf16)a.v[k];
+        *(bf16x8*)(tile + rr * TP_PITCH + c * 16) = v;
+    }
+    __syncthreads();
+    tp_write_out(tile, dst_t + (int64_t)bi * cols * rows, rows, c0, r0);
 }
 }  // namespace star
 
@@ -1827,6 +1875,66 @@ extern "C" int star_colsum(const void* x, int dtype, int64_t M, int N, int64_t l
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, (int)nchunk, N, out);
     STAR_LAUNCH_CHECK("star_colsum");
+    return STAR_OK;
+}
+
+extern "C" int star_colsum_batched(const void* const* x_list, int nbatch, int dtype, int64_t M, int N, int64_t ld,
+                                   float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace star;
+    STAR_REQUIRE(x_list && out && workspace, "star_colsum_batched: null pointer");
+    STAR_REQUIRE(nbatch >= 1 && nbatch <= CS_MAX_BATCH, "star_colsum_batched: nbatch = %d (1..%d)", nbatch, CS_MAX_BATCH);
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_colsum_batched: bad dtype %d", dtype);
+    STAR_REQUIRE(M >= 1 && N >= 8 && N % 8 == 0 && ld >= N && ld % 8 == 0,
+                 "star_colsum_batched: bad shape M=%lld N=%d ld=%lld", (long long)M, N, (long long)ld);
+    ColsumList l = {};
+    for (int i = 0; i < nbatch; ++i) {
+        STAR_REQUIRE(x_list[i] && ((uintptr_t)x_list[i] & (dtype == STAR_DT_BF16 ? 15 : 31)) == 0,
+                     "star_colsum_batched: matrix %d is null or not aligned to 8 elements", i);
+        l.x[i] = x_list[i];
+    }
+    const int64_t nchunk = (M + CS_ROWS - 1) / CS_ROWS;
+    STAR_REQUIRE(nchunk <= 65535, "star_colsum_batched: M=%lld too large", (long long)M);
+    if (workspace_bytes < (size_t)nbatch * star_colsum_workspace(M, N)) {
+        set_error("star_colsum_batched: workspace %zu < %zu bytes", workspace_bytes,
+                  (size_t)nbatch * star_colsum_workspace(M, N));
+        return STAR_ERR_WORKSPACE;
+    }
+    const dim3 grid(cdiv(N, 256), (unsigned)nchunk, (unsigned)nbatch);
+    if (dtype == STAR_DT_BF16)
+        hipLaunchKernelGGL(colsum_part_batched_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, l, ld, M, N,
+                           (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_part_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, l, ld, M, N,
+                           (float*)workspace);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 256), nbatch), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (int)nchunk, N, out);
+    STAR_LAUNCH_CHECK("star_colsum_batched");
+    return STAR_OK;
+}
+
+extern "C" int star_transpose_list_bf16(const void* const* src_list, int n, int dtype, int rows, int cols, void* dst_t,
+                                        void* stream) {
+    using namespace star;
+    STAR_REQUIRE(src_list && dst_t, "star_transpose_list_bf16: null pointer");
+    STAR_REQUIRE(n >= 1 && n <= CS_MAX_BATCH, "star_transpose_list_bf16: n = %d (1..%d)", n, CS_MAX_BATCH);
+    STAR_REQUIRE(dtype == STAR_DT_BF16 || dtype == STAR_DT_F32, "star_transpose_list_bf16: bad dtype %d", dtype);
+    STAR_REQUIRE(rows >= 64 && cols >= 64 && rows % 64 == 0 && cols % 64 == 0,
+                 "star_transpose_list_bf16: rows = %d, cols = %d must be multiples of 64", rows, cols);
+    STAR_REQUIRE(((uintptr_t)dst_t & 15) == 0, "star_transpose_list_bf16: dst_t must be 16-byte aligned");
+    ColsumList l = {};
+    for (int i = 0; i < n; ++i) {
+        STAR_REQUIRE(src_list[i] && ((uintptr_t)src_list[i] & (dtype == STAR_DT_BF16 ? 15 : 31)) == 0,
+                     "star_transpose_list_bf16: matrix %d is null or not aligned to 8 elements", i);
+        l.x[i] = src_list[i];
+    }
+    const dim3 grid(cols / 64, rows / 64, n);
+    if (dtype == STAR_DT_BF16)
+        hipLaunchKernelGGL(transpose_list_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, l, rows, cols,
+                           (__bf16*)dst_t);
+    else
+        hipLaunchKernelGGL(transpose_list_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, l, rows, cols,
+                           (__bf16*)dst_t);
+    STAR_LAUNCH_CHECK("star_transpose_list_bf16");
     return STAR_OK;
 }
 

@@ -1224,6 +1224,47 @@ def colsum(x2d):
     return out
 
 
+def transpose_cat_bf16(weights):
+    """[w_i [in, out] for i] (contiguous, all fp32 or all bf16, one shape) -> bf16 [len * out, in]: every weight
+    transposed, side by side, in one launch (star_transpose_list_bf16)."""
+    n = len(weights)
+    _need_cuda(*weights)
+    w0 = weights[0]
+    if n < 1 or n > TN_MAX_BATCH or w0.dim() != 2 or w0.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError(f"transpose_cat_bf16: 1..{TN_MAX_BATCH} 2-D bf16 / fp32 matrices")
+    for w in weights:
+        if w.shape != w0.shape or w.dtype != w0.dtype or not w.is_contiguous() or w.device != w0.device:
+            raise ValueError("transpose_cat_bf16: the matrices must be contiguous and share one shape, dtype and device")
+    rows, cols = w0.shape
+    out = torch.empty((n * cols, rows), dtype=torch.bfloat16, device=w0.device)
+    pw = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+    check(lib().star_transpose_list_bf16(pw, n, DT_BF16 if w0.dtype == torch.bfloat16 else DT_F32, rows, cols, ptr(out),
+                                         stream_ptr()), "star_transpose_list_bf16")
+    return out
+
+
+def colsum_batched(xs):
+    """star_colsum of up to 16 matrices of one shape, dtype and row stride in one pair of launches -> fp32 [len(xs), N]
+    (each row bit-identical to colsum of that matrix)."""
+    nb = len(xs)
+    _need_cuda(*xs)
+    x0 = xs[0]
+    if nb < 1 or nb > TN_MAX_BATCH or x0.dim() != 2 or x0.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError(f"colsum_batched: 1..{TN_MAX_BATCH} 2-D bf16 / fp32 matrices")
+    for x in xs:
+        if x.shape != x0.shape or x.dtype != x0.dtype or x.stride() != x0.stride() or x.stride(1) != 1 \
+                or x.device != x0.device:
+            raise ValueError("colsum_batched: the matrices must share one shape, dtype, row stride and device")
+    M, N = x0.shape
+    out = torch.empty((nb, N), dtype=torch.float32, device=x0.device)
+    wsb = nb * lib().star_colsum_workspace(M, N)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x0.device)
+    px = (C.c_void_p * nb)(*[x.data_ptr() for x in xs])
+    check(lib().star_colsum_batched(px, nb, DT_BF16 if x0.dtype == torch.bfloat16 else DT_F32, M, N, x0.stride(0),
+                                    ptr(out), ptr(ws), wsb, stream_ptr()), "star_colsum_batched")
+    return out
+
+
 def gemm_nt_bf16(a2d, wt, bias=None):
     """out[M,N] = a2d[M,K] @ wt[N,K]^T + bias[N] on this library's 256 x 256 MFMA tile (star_gemm_nt_bf16)."""
     _need_cuda(a2d, wt, bias)
@@ -1294,11 +1335,11 @@ class _DeferredWeightGrads:
     for torch.autograd.grad() callers and gradient hooks on the weights (hook-based DDP) do not see them."""
 
     def __init__(self):
-        self.items = []              # (x2, g2, weight)
+        self.items = []              # (x2, g2, weight, bias or None)
         self.armed = False
 
-    def add(self, x2, g2, weight):
-        self.items.append((x2, g2, weight))
+    def add(self, x2, g2, weight, bias=None):
+        self.items.append((x2, g2, weight, bias))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
@@ -1306,9 +1347,9 @@ class _DeferredWeightGrads:
     def flush(self):
         items, self.items, self.armed = self.items, [], False
         groups = {}
-        for x2, g2, w in items:
+        for x2, g2, w, b in items:
             groups.setdefault((tuple(x2.shape), x2.stride(0), tuple(g2.shape), g2.stride(0), x2.device), []).append(
-                (x2, g2, w))
+                (x2, g2, w, b))
         with torch.no_grad():
             for grp in groups.values():
                 R, M = grp[0][0].shape
@@ -1323,16 +1364,27 @@ class _DeferredWeightGrads:
                 per = max(1, TN_MAX_BATCH // ks)
                 for at in range(0, len(grp), per):
                     part = grp[at:at + per]
-                    dws = gemm_tn_batched([x for x, _, _ in part], [g for _, g, _ in part], ks)
+                    dws = gemm_tn_batched([it[0] for it in part], [it[1] for it in part], ks)
+                    with_bias = [it for it in part if it[3] is not None]
+                    dbs = colsum_batched([it[1] for it in with_bias]) if with_bias else None
                     by_dtype = {}
-                    for i, (_, _, w) in enumerate(part):
-                        if w.dtype not in by_dtype:
-                            by_dtype[w.dtype] = dws if w.dtype == torch.float32 else dws.to(w.dtype)
-                        dw = by_dtype[w.dtype][i]
-                        if w.grad is None:
-                            w.grad = dw
-                        else:
-                            w.grad.add_(dw)
+
+                    def cast(t, dtype, tag):
+                        if (tag, dtype) not in by_dtype:
+                            by_dtype[(tag, dtype)] = t if dtype == torch.float32 else t.to(dtype)
+                        return by_dtype[(tag, dtype)]
+
+                    nbias = 0
+                    for i, (_, _, w, b) in enumerate(part):
+                        grads = [(w, cast(dws, w.dtype, "w")[i])]
+                        if b is not None:
+                            grads.append((b, cast(dbs, b.dtype, "b")[nbias]))
+                            nbias += 1
+                        for prm, gr in grads:
+                            if prm.grad is None:
+                                prm.grad = gr
+                            else:
+                                prm.grad.add_(gr)
 
 
 _deferred_wgrads = _DeferredWeightGrads()
@@ -1364,6 +1416,7 @@ class _Conv1D(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         ctx.b_dtype = bias.dtype
+        ctx.bias_ref = bias if ctx.defer_wgrad else None
         return y.view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -1379,7 +1432,12 @@ class _Conv1D(torch.autograd.Function):
             dx = torch.mm(g2, weight.to(g2.dtype).t()).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             if ctx.defer_wgrad and weight.is_leaf and _tn_batch_fits(x2, g2):
-                _deferred_wgrads.add(x2, g2, weight)         # formed with the other layers' at the end of backward
+                # formed with the other layers' at the end of backward; the bias gradient (a column sum of the same
+                # g) goes with it when the bias is a leaf too
+                b = ctx.bias_ref if (ctx.needs_input_grad[2] and ctx.bias_ref is not None and ctx.bias_ref.is_leaf) else None
+                _deferred_wgrads.add(x2, g2, weight, b)
+                if b is not None:
+                    return dx, None, None, None, None
             else:
                 dw = torch.mm(x2.t(), g2).to(weight.dtype)
         if ctx.needs_input_grad[2]:

@@ -667,6 +667,10 @@ def test_gemm_tn_batched_vs_fp32(ops, nb, ks, R, M, N, pad):
         ref = xs[i].double().t() @ gs[i].double()
         err = (out[i].double() - ref).abs().max().item()
         assert err <= 1e-4 * ref.abs().max().item(), (i, err)
+    # the bias gradients that go with them: one launch pair, each row bit-identical to star_colsum of that matrix
+    cs = ops.colsum_batched(gs)
+    for i in range(nb):
+        assert torch.equal(cs[i], ops.colsum(gs[i]))
     with pytest.raises(ValueError):
         ops.gemm_tn_batched(xs, gs[:-1] + [gs[-1][:, :N - 8]], ks)         # mixed shapes
     with pytest.raises(ValueError):
@@ -720,3 +724,16 @@ def test_deferred_projection_weight_grads_equal_immediate(ops):
     x32 = torch.randn(2, 8, d, device=DEV, requires_grad=True)
     m32(x32.bfloat16().float(), encoder_hidden_states=mem.detach().float())[0].sum().backward()
     assert m32.q_attn.weight.grad is not None and m32.c_proj.weight.grad is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_cat_bf16_equals_torch(ops, dtype):
+    """star_transpose_list_bf16 (the all-layer c_attn weight of share_encoder_kv, rebuilt once per optimizer step)
+    against cat(dim=1).t().contiguous() of the bf16-cast weights: bit-identical."""
+    g = torch.Generator(device=DEV).manual_seed(17)
+    ws = [torch.randn(192, 320, device=DEV, generator=g).to(dtype) for _ in range(5)]
+    got = ops.transpose_cat_bf16(ws)
+    want = torch.cat([w.to(torch.bfloat16) for w in ws], dim=1).t().contiguous()
+    assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.transpose_cat_bf16([w[:, :200] for w in ws])
