@@ -307,7 +307,7 @@ def _kv_weight_cache(mods, dt):
                 wt_all = ops.transpose_cat_bf16(ws)          # one launch (cat + strided copy: 14 + 40 us at nl = 4)
             else:
                 wt_all = torch.cat([w.to(dt) for w in ws], dim=1).t().contiguous()
-            b_all = torch.cat([m.c_attn.bias.detach().to(torch.float32) for m in mods], dim=0).contiguous()
+            b_all = torch.cat([m.c_attn.bias.detach() for m in mods], dim=0).to(torch.float32)   # (cat, then ONE cast)
         ent = (tag, wt_all, b_all)
         if len(_KV_WEIGHTS) > 64:
             _KV_WEIGHTS.clear()
