@@ -449,6 +449,35 @@ def test_fuzz_projection_gemm_and_colsum(ops):
             assert err <= 1e-5 * max(x.float().abs().sum(0).max().item(), 1.0), f"colsum case {n} ({M}x{N} {dt}): {err}"
 
 
+def test_fuzz_tn_batched_and_transposes(ops):
+    """star_gemm_tn_batched_bf16 ([x_i^T g_i for i], fp32), star_colsum_batched and star_transpose_list_bf16 over random
+    batch sizes, r-range counts, shapes and row strides against fp64 / torch on the same operands."""
+    for n, rng in _cases("tnb"):
+        ks = int(rng.choice([1, 1, 2, 4]))
+        nb = int(rng.integers(1, 16 // ks + 1))
+        R = 64 * ks * int(rng.integers(1, 9))
+        M = int(rng.choice([128, 136, 256, 264, 512, 1024]))
+        N = int(rng.choice([128, 200, 256, 384, 1024]))
+        pa, pb = int(rng.choice([0, 0, 8, 64])), int(rng.choice([0, 0, 8, 64]))
+        g = _tg(rng)
+        xs = [torch.randn(R, M + pa, generator=g).to(torch.bfloat16).to(DEV)[:, :M] for _ in range(nb)]
+        gs = [torch.randn(R, N + pb, generator=g).to(torch.bfloat16).to(DEV)[:, :N] for _ in range(nb)]
+        out = ops.gemm_tn_batched(xs, gs, ks)
+        what = f"tnb case {n} (nb{nb} ks{ks} R{R} M{M} N{N} pads {pa},{pb})"
+        for i in range(nb):
+            ref = xs[i].double().t() @ gs[i].double()
+            err = (out[i].double() - ref).abs().max().item()
+            assert err <= 1e-4 * max(ref.abs().max().item(), 1.0), f"{what} product {i}: {err}"
+        cs = ops.colsum_batched(gs)
+        for i in range(nb):
+            assert torch.equal(cs[i], ops.colsum(gs[i])), f"{what} colsum {i}"
+        dt = torch.bfloat16 if rng.random() < 0.5 else torch.float32
+        rows, cols = 64 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 6))
+        ws = [torch.randn(rows, cols, generator=g).to(dt).to(DEV) for _ in range(nb)]
+        want = torch.cat([w.to(torch.bfloat16) for w in ws], dim=1).t().contiguous()
+        assert torch.equal(ops.transpose_cat_bf16(ws), want), f"{what} transpose {rows}x{cols} {dt}"
+
+
 def _step_close(a, b, what, tol=3e-2, floor=0.0):
     a, b = a.detach().float().cpu().numpy(), b.detach().numpy()
     scale = max(np.abs(b).max(), floor) + 1e-12
