@@ -576,11 +576,18 @@ def roofline_legs(ops, scorer, inp, wl, rate, dev, scorer_leg, evict):
         us = event_time_us(fn, evict=evict)
         e = {"name": name, "kernel": kernel, "avg_us": round(us, 2), "warm_us": round(warm, 2)}
         if flops is not None:
+            # the binding roof is the one whose time at peak is longer: flops / MFMA peak against bytes / HBM peak (the
+            # attention core at these shapes has ~95 FLOP per byte, below the ~310 of the ridge: HBM binds it)
             tf = flops / (us * 1e-6) / 1e12
-            e.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                     frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flops)
             gb = bytes_ / (us * 1e-6) / 1e9
-            e.update(hbm_gbs=round(gb, 1), hbm_frac=round(gb / HBM_PEAK_GBS, 4), bytes_per_launch=bytes_)
+            if bytes_ / (HBM_PEAK_GBS * 1e9) > flops / (MFMA_BF16_PEAK_TFLOPS * 1e12):
+                e.update(bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=round(gb / HBM_PEAK_GBS, 4))
+            else:
+                e.update(bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4))
+            e.update(mfma_tflops=round(tf, 2), mfma_frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flop_per_launch=flops,
+                     hbm_gbs=round(gb, 1), hbm_frac=round(gb / HBM_PEAK_GBS, 4), bytes_per_launch=bytes_)
         else:
             gb = bytes_ / (us * 1e-6) / 1e9
             e.update(bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gb / HBM_PEAK_GBS, 4),
