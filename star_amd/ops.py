@@ -1289,10 +1289,10 @@ TN_MAX_BATCH = 16            # star_gemm_tn_batched_bf16: products (times r rang
 _TN_MAX_ROWS = 7168          # rows of one r range
 
 
-def gemm_tn_batched(a_list, b_list, ksplit: int = 1):
+def gemm_tn_batched(a_list, b_list, ksplit: int = 1, reduce: bool = True):
     """[a_i^T @ b_i for i] in one launch of this library's TN GEMM (star_gemm_tn_batched_bf16): a_i [R, M], b_i [R, N]
     bf16, all of one shape and row stride -> fp32 [len(a_list), M, N].  ksplit: r ranges per product (their partial
-    products are added here, in order)."""
+    products are added here, in order; reduce=False returns them as they are, [len(a_list), ksplit, M, N])."""
     nb = len(a_list)
     if nb < 1 or len(b_list) != nb or nb * ksplit > TN_MAX_BATCH:
         raise ValueError(f"gemm_tn_batched: {nb} products x {ksplit} ranges (at most {TN_MAX_BATCH} together)")
@@ -1311,6 +1311,8 @@ def gemm_tn_batched(a_list, b_list, ksplit: int = 1):
     pb = (C.c_void_p * nb)(*[b.data_ptr() for b in b_list])
     check(lib().star_gemm_tn_batched_bf16(pa, pb, nb, ksplit, R, M, N, a0.stride(0), b0.stride(0), ptr(out),
                                           stream_ptr()), "star_gemm_tn_batched_bf16")
+    if not reduce:
+        return out.view(nb, ksplit, M, N)
     return out if ksplit == 1 else out.view(nb, ksplit, M, N).sum(1)
 
 
@@ -1364,14 +1366,22 @@ class _DeferredWeightGrads:
                 per = max(1, TN_MAX_BATCH // ks)
                 for at in range(0, len(grp), per):
                     part = grp[at:at + per]
-                    dws = gemm_tn_batched([it[0] for it in part], [it[1] for it in part], ks)
+                    raw = gemm_tn_batched([it[0] for it in part], [it[1] for it in part], ks, reduce=False)
+                    wdt = {it[2].dtype for it in part}
+                    if ks == 2 and len(wdt) == 1:
+                        # the sum of the two ranges and the cast to the weights' dtype in one pass over the partials
+                        # (one fp32 add, one rounding: the same value as sum-then-cast)
+                        dws = torch.add(raw[:, 0], raw[:, 1], out=torch.empty(raw.shape[0], M, N, dtype=wdt.pop(),
+                                                                              device=raw.device))
+                    else:
+                        dws = raw[:, 0] if ks == 1 else raw.sum(1)
                     with_bias = [it for it in part if it[3] is not None]
                     dbs = colsum_batched([it[1] for it in with_bias]) if with_bias else None
                     by_dtype = {}
 
                     def cast(t, dtype, tag):
                         if (tag, dtype) not in by_dtype:
-                            by_dtype[(tag, dtype)] = t if dtype == torch.float32 else t.to(dtype)
+                            by_dtype[(tag, dtype)] = t if dtype == t.dtype else t.to(dtype)
                         return by_dtype[(tag, dtype)]
 
                     nbias = 0
