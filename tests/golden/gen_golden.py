@@ -523,6 +523,26 @@ def gen_gather_ln():
              out=out, gout=gout, dhidden=hidden.grad, dweight=ln_f.weight.grad, dbias=ln_f.bias.grad)
 
 
+def gen_select_given_counts():
+    """apply_nugget_compression with the nugget counts GIVEN (n_nugget=, as the word-delimiter-driven inference calls
+    at w2v_asr.py:381 and :452 pass them: max(#delimiters, n_tok // 20 [+ 1])) instead of derived from the rate:
+    no clamp to n_tok is applied on this path (w2v_asr.py:218-221 is skipped), so a count may exceed the valid frames
+    and its kept set then reaches into padded frames."""
+    asr = w2v_asr.W2VASRModel
+    g = torch.Generator().manual_seed(97)
+    for name, t, lengths, counts in (("a", 60, [60, 41, 17], [7, 3, 1]),
+                                     ("b", 130, [130, 129, 64, 5], [9, 40, 4, 2]),
+                                     ("over", 24, [24, 6, 10], [5, 8, 10])):          # 8 > 6 valid frames
+        scores = torch.randn(len(lengths), t, generator=g)
+        mask = len_mask(lengths, t)
+        me = SimpleNamespace(nugget_compress_rate=4)
+        nmask, idx, sg = asr.apply_nugget_compression(me, torch.zeros(len(lengths), t, 2), mask,
+                                                      nugget_scores=scores.clone(), n_nugget=torch.tensor(counts))
+        table, pos = asr.add_nugget_type_embedding(torch.zeros(len(lengths), t, 2), idx, nmask)
+        save("selectn_" + name, scores=scores, lengths=np.array(lengths), n_nugget=np.array(counts),
+             nugget_mask=nmask, indices=idx, scores_gather=sg, type_table=table, positions=pos)
+
+
 def gen_head_mask():
     """MyGPT2Attention._attn (my_transformer.py:535-603) with a head mask: `attn_weights = attn_weights * head_mask`
     after the dropout (:598-599), in the shape HF's get_head_mask hands to a block ([1, h, 1, 1], one factor per head;
@@ -552,6 +572,6 @@ def gen_head_mask():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed, gen_resize_grad,
-               gen_valid_indices, gen_xattn_drop, gen_gather_ln, gen_head_mask):
+               gen_valid_indices, gen_xattn_drop, gen_gather_ln, gen_head_mask, gen_select_given_counts):
         if not only or fn.__name__ in only:
             fn()

@@ -64,6 +64,29 @@ def test_select_golden(ops, name, use_mask):
                                    g["scores_gather"])
 
 
+@pytest.mark.parametrize("name", ["selectn_a", "selectn_b", "selectn_over"])
+def test_select_given_counts_golden(ops, name):
+    """apply_nugget_compression(..., n_nugget=) (w2v_asr.py:381,452: counts from the word delimiters, no clamp to the
+    valid frames): kernel = oracle bit for bit, = the reference wherever its answer does not hinge on its unstable sort,
+    through the drop-in method itself."""
+    from star_amd.nugget import NuggetOpsMixin
+    g = load(name)
+    B, T = g["scores"].shape
+    mask = lmask(g["lengths"], T)
+    me = NuggetOpsMixin()
+    me.nugget_compress_rate = 4
+    nmask, idx, sg = me.apply_nugget_compression(torch.zeros(B, T, 2, device=DEV), dev(mask), nugget_scores=dev(g["scores"]),
+                                                 n_nugget=dev(g["n_nugget"]))
+    nmask, idx, sg = (t.cpu().numpy() for t in (nmask, idx, sg))
+    o_mask, o_idx, o_sg = orc.topk_select(g["scores"], mask, n_nugget=g["n_nugget"])
+    np.testing.assert_array_equal(nmask, o_mask)
+    np.testing.assert_array_equal(idx, o_idx)
+    np.testing.assert_array_equal(sg, o_sg)
+    np.testing.assert_array_equal(nmask, g["nugget_mask"])
+    assert_select_equal_up_to_ties(idx, g["indices"], nmask, select_keys(g["scores"], g["lengths"]), sg,
+                                   g["scores_gather"])
+
+
 @pytest.mark.parametrize("B,T,rate", [(8, 1500, 4), (8, 1500, 2), (4, 1500, 12), (3, 3000, 8), (5, 257, 4), (2, 8191, 4),
                                       # around the 1024 threads of a workgroup
                                       (3, 1023, 4), (3, 1024, 2), (2, 1025, 8), (2, 2049, 4), (4, 5, 1)])

@@ -86,6 +86,21 @@ def test_select(name):
         np.testing.assert_array_equal(pos, g["positions"])
 
 
+@pytest.mark.parametrize("name", ["selectn_a", "selectn_b", "selectn_over"])
+def test_select_given_counts(name):
+    # apply_nugget_compression(..., n_nugget=) as the word-delimiter inference calls pass it (w2v_asr.py:381,452): the
+    # counts are used as given, without the clamp to the valid frames (selectn_over: 8 nuggets of 6 valid frames)
+    g = load(name)
+    t = g["scores"].shape[1]
+    mask = lmask(g["lengths"], t)
+    nmask, idx, sg = orc.topk_select(g["scores"], mask, n_nugget=g["n_nugget"])
+    np.testing.assert_array_equal(nmask, g["nugget_mask"])
+    assert_select_equal_up_to_ties(idx, g["indices"], nmask, select_keys(g["scores"], g["lengths"]), sg, g["scores_gather"])
+    ref_table, ref_pos = orc.type_table(t, g["indices"], g["nugget_mask"])
+    np.testing.assert_array_equal(ref_table, g["type_table"])
+    np.testing.assert_array_equal(ref_pos, g["positions"])
+
+
 @pytest.mark.parametrize("name", CIF)
 def test_cif(name):
     g = load(name)
