@@ -288,9 +288,11 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                key_mask: torch.Tensor | None, scorer_logits: torch.Tensor | None,
                limit_cross_attn: bool = False, scale: bool = True,
                drop_mask: torch.Tensor | None = None, drop_p: float = 0.0,
-               head_mask: torch.Tensor | None = None):
+               head_mask: torch.Tensor | None = None, inverse_layer_idx: int | None = None):
     """Score-biased cross-attention core (my_transformer.py:535-603, cross-attention branch).  head_mask (None on
     the reference's own call path): multiplied into the weights after the dropout (my_transformer.py:598-599).
+    scale: scale_attn_weights (1/sqrt(hd), :538-541); inverse_layer_idx: layer_idx when
+    scale_attn_by_inverse_layer_idx is set (a further 1/(layer_idx+1)), else None.
 
     q [B,h,L,hd], k/v [B,h,K,hd], key_mask [B,K] bool (True = attend), scorer_logits [B,Kb]
     with Kb <= K (zero-extended, my_transformer.py:114-125 variant).  drop_mask [B,h,L,K] (1 = keep) with
@@ -301,6 +303,8 @@ def xattn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     a = q @ k.transpose(-1, -2)
     if scale:
         a = a / (v.shape[-1] ** 0.5)
+    if inverse_layer_idx is not None:            # scale_attn_by_inverse_layer_idx (my_transformer.py:544-545)
+        a = a / float(inverse_layer_idx + 1)
     lq, lk = a.shape[-2], a.shape[-1]
     fmin = torch.finfo(a.dtype).min
     if limit_cross_attn:

@@ -523,6 +523,30 @@ def gen_gather_ln():
              out=out, gout=gout, dhidden=hidden.grad, dweight=ln_f.weight.grad, dbias=ln_f.bias.grad)
 
 
+def gen_xattn_scaling():
+    """MyGPT2Attention._attn with the two scaling switches off their defaults (my_transformer.py:538-545):
+    scale_attn_weights=False (no 1/sqrt(hd)) and scale_attn_by_inverse_layer_idx=True with layer_idx = 2 (a further
+    1/3), with the score bias and, in one case, the infinite-lookback mask."""
+    att = my_transformer.MyGPT2Attention
+    g = torch.Generator().manual_seed(113)
+    for name, b, h, lq, lk, hd, klen, ilk, saw, inv, li in (("noscale", 2, 2, 5, 8, 8, [8, 5], False, False, False, 0),
+                                                            ("invlayer", 2, 3, 6, 9, 16, [9, 7], True, True, True, 2)):
+        q = (torch.randn(b, h, lq, hd, generator=g) * (0.4 if not saw else 1.0)).requires_grad_()
+        k = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        v = torch.randn(b, h, lk, hd, generator=g).requires_grad_()
+        sc = torch.randn(b, lk, generator=g).requires_grad_()
+        gout = torch.randn(b, h, lq, hd, generator=g)
+        kmask = len_mask(klen, lk)
+        add = (1.0 - kmask[:, None, None, :].to(torch.float32)) * torch.finfo(torch.float32).min
+        me = SimpleNamespace(scale_attn_weights=saw, scale_attn_by_inverse_layer_idx=inv,
+                             is_cross_attention=True, layer_idx=li, attn_dropout=torch.nn.Identity())
+        o, pw = att._attn(me, q, k, v, add, None, sc, limit_cross_attn=ilk)
+        (o * gout).sum().backward()
+        save("scaling_" + name, q=q, k=k, v=v, scores=sc, key_lengths=np.array(klen), ilk=np.array(ilk),
+             scale_attn_weights=np.array(saw), inverse_layer_idx=np.array(inv), layer_idx=np.array(li),
+             gout=gout, o=o, p=pw, dq=q.grad, dk=k.grad, dv=v.grad, dscores=sc.grad)
+
+
 def gen_select_given_counts():
     """apply_nugget_compression with the nugget counts GIVEN (n_nugget=, as the word-delimiter-driven inference calls
     at w2v_asr.py:381 and :452 pass them: max(#delimiters, n_tok // 20 [+ 1])) instead of derived from the rate:
@@ -572,6 +596,7 @@ def gen_head_mask():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (gen_select, gen_cif, gen_xattn, gen_scorer, gen_e2e, gen_cif_agg, gen_type_embed, gen_resize_grad,
-               gen_valid_indices, gen_xattn_drop, gen_gather_ln, gen_head_mask, gen_select_given_counts):
+               gen_valid_indices, gen_xattn_drop, gen_gather_ln, gen_head_mask, gen_select_given_counts,
+               gen_xattn_scaling):
         if not only or fn.__name__ in only:
             fn()

@@ -737,3 +737,39 @@ def test_transpose_cat_bf16_equals_torch(ops, dtype):
     assert got.shape == want.shape and torch.equal(got, want)
     with pytest.raises(ValueError):
         ops.transpose_cat_bf16([w[:, :200] for w in ws])
+
+
+@pytest.mark.parametrize("name", ["scaling_noscale", "scaling_invlayer"])
+def test_score_biased_attn_scaling_switches_golden(ops, name):
+    """scale_attn_weights=False and scale_attn_by_inverse_layer_idx=True with layer_idx = 2 (my_transformer.py:538-545)
+    through score_biased_attn's own arguments, against the oracle on the bf16-rounded operands (2e-2) and the
+    reference's numbers (5e-2); reference run: tests/golden/gen_golden.py gen_xattn_scaling."""
+    import os
+    from star_amd.nugget import score_biased_attn
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    q, k, v, sc, gout = (torch.from_numpy(g[n]) for n in ("q", "k", "v", "scores", "gout"))
+    saw, inv, li, ilk = bool(g["scale_attn_weights"]), bool(g["inverse_layer_idx"]), int(g["layer_idx"]), bool(g["ilk"])
+    hd = q.shape[-1]
+    pad = lambda t: torch.nn.functional.pad(t, (0, 64 - hd))
+    c = (64 / hd) ** 0.5 if saw else 1.0          # the kernel sees head dim 64 after the zero padding
+    kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
+    qr = (bf16_round(q * c) / c).requires_grad_()
+    kr, vr = (bf16_round(t).requires_grad_() for t in (k, v))
+    scr = sc.clone().requires_grad_()
+    o_ref, p_ref = orc.xattn_core(qr, kr, vr, kmask, scr, ilk, scale=saw, inverse_layer_idx=li if inv else None)
+    (o_ref * bf16_round(gout)).sum().backward()
+    qd, kd, vd = (pad(t).to(torch.bfloat16).to(DEV).requires_grad_() for t in (q * c, k, v))
+    scd = sc.to(DEV).requires_grad_()
+    add = ((1.0 - kmask.float()) * torch.finfo(torch.float32).min).view(kmask.shape[0], 1, 1, -1).to(DEV)
+    o, p = score_biased_attn(qd, kd, vd, add, None, scd, limit_cross_attn=ilk, scale_attn_weights=saw,
+                             scale_attn_by_inverse_layer_idx=inv, layer_idx=li, output_attentions=True)
+    o.backward(pad(gout).to(torch.bfloat16).to(DEV))
+    f = lambda t: t.float().cpu()[..., :hd].numpy()
+    tol = dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(f(o.detach()), o_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(p.detach().float().cpu().numpy(), p_ref.detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(f(qd.grad) * c, qr.grad.numpy(), **tol)
+    np.testing.assert_allclose(f(kd.grad), kr.grad.numpy(), **tol)
+    np.testing.assert_allclose(f(vd.grad), vr.grad.numpy(), **tol)
+    np.testing.assert_allclose(scd.grad.cpu().numpy(), scr.grad.numpy(), **tol)
+    np.testing.assert_allclose(f(o.detach()), g["o"], rtol=5e-2, atol=5e-2)

@@ -159,6 +159,21 @@ def test_xattn_head_mask(name):
         np.testing.assert_allclose(got.numpy(), g[want], err_msg=want, **tol)
 
 
+@pytest.mark.parametrize("name", ["scaling_noscale", "scaling_invlayer"])
+def test_xattn_scaling_switches(name):
+    # scale_attn_weights=False / scale_attn_by_inverse_layer_idx=True with layer_idx 2 (my_transformer.py:538-545)
+    g = load(name)
+    q, k, v, sc = (torch.from_numpy(g[n]).requires_grad_() for n in ("q", "k", "v", "scores"))
+    kmask = torch.from_numpy(lmask(g["key_lengths"], k.shape[2]))
+    o, p = orc.xattn_core(q, k, v, kmask, sc, bool(g["ilk"]), scale=bool(g["scale_attn_weights"]),
+                          inverse_layer_idx=int(g["layer_idx"]) if bool(g["inverse_layer_idx"]) else None)
+    (o * torch.from_numpy(g["gout"])).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-6)
+    for got, want in ((o.detach(), "o"), (p.detach(), "p"), (q.grad, "dq"), (k.grad, "dk"), (v.grad, "dv"),
+                      (sc.grad, "dscores")):
+        np.testing.assert_allclose(got.numpy(), g[want], err_msg=want, **tol)
+
+
 def test_scorer():
     g = load("scorer_small")
     x, w1, b1, w2, b2 = (torch.from_numpy(g[n]).requires_grad_() for n in ("x", "w1", "b1", "w2", "b2"))
