@@ -773,3 +773,47 @@ def test_score_biased_attn_scaling_switches_golden(ops, name):
     np.testing.assert_allclose(f(vd.grad), vr.grad.numpy(), **tol)
     np.testing.assert_allclose(scd.grad.cpu().numpy(), scr.grad.numpy(), **tol)
     np.testing.assert_allclose(f(o.detach()), g["o"], rtol=5e-2, atol=5e-2)
+
+
+def test_deferred_projection_weight_grads_under_graph_capture(ops):
+    """The end-of-backward callback of defer_projection_weight_grads runs inside a HIP-graph capture like the rest of
+    the backward pass (tools/f1_stack.py times it that way): a captured forward + backward, replayed on new inputs,
+    leaves the gradients of an eager run on those inputs in the captured .grad tensors."""
+    from star_amd.nugget import NuggetCrossAttention, defer_projection_weight_grads
+    torch.manual_seed(11)
+    B, L, K, d, h, nl = 2, 64, 40, 256, 4, 2
+    mods = [NuggetCrossAttention(d, h, layer_idx=i).to(DEV, torch.bfloat16) for i in range(nl)]
+    defer_projection_weight_grads(mods)
+    mem = torch.randn(B, K, d, device=DEV).bfloat16()
+    x = torch.randn(B, L, d, device=DEV).bfloat16()
+    gout = torch.randn(B, L, d, device=DEV).bfloat16()
+    params = [p for m in mods for p in m.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        outs = [m(x, encoder_hidden_states=mem)[0] for m in mods]
+        torch.autograd.backward(outs, [gout] * nl)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    captured = [p.grad for p in params]
+    assert all(g is not None for g in captured)
+    for trial in range(2):
+        x.copy_(torch.randn(B, L, d, device=DEV).bfloat16())
+        mem.copy_(torch.randn(B, K, d, device=DEV).bfloat16())
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [g.clone() for g in captured]
+        step()                                    # eager, same inputs (rebinds .grad: `captured` keeps the graph's)
+        torch.cuda.synchronize()
+        for p, a in zip(params, got):
+            assert torch.equal(a, p.grad), trial
